@@ -1,0 +1,175 @@
+/*
+ * semidetr_hip.h -- C ABI of libsemidetr_hip.so: the MI355X (gfx950) native hot path of Semi-DETR.
+ *
+ * Drop-in boundary: plain pointers + sizes, no torch types.  All pointers are DEVICE pointers unless
+ * the parameter is documented as host.  `stream` is a hipStream_t passed as void* (NULL = the null
+ * stream).  Every call is asynchronous on `stream`, keeps no global state between calls (apart from a
+ * thread-local last-error string) and is re-entrant.  Return value: 0 on success, otherwise a
+ * SEMIDETR_E_* code (negative: argument/precondition error detected on the host; positive: the
+ * hipError_t returned by the launch).  semidetr_last_error() gives the message for the calling thread.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the Semi-DETR tree).
+ */
+#ifndef SEMIDETR_HIP_H
+#define SEMIDETR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEMIDETR_OK 0
+#define SEMIDETR_E_BADARG (-1)      /* null pointer / non-positive size / unsupported combination   */
+#define SEMIDETR_E_TOOLARGE (-2)    /* an index would overflow the 32-bit arithmetic used on device  */
+#define SEMIDETR_E_NODEVICE (-3)    /* no HIP device available                                        */
+
+#define SEMIDETR_ABI_VERSION 1
+
+int semidetr_abi_version(void);
+const char *semidetr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention (MSDA).
+ *
+ * Replaces  ms_deformable_im2col_cuda   detr_od/models/utils/ops/src/cuda/ms_deform_im2col_cuda.cuh:923-954
+ *           ms_deformable_col2im_cuda   detr_od/models/utils/ops/src/cuda/ms_deform_im2col_cuda.cuh:956-1327
+ * i.e. the launchers behind ms_deform_attn_cuda_forward/backward (ms_deform_attn_cuda.cu:20-153), which
+ * the pybind module MultiScaleDeformableAttention exports (src/vision.cpp:13-16).
+ *
+ * Layouts (contiguous, row-major), exactly the reference's:
+ *   value          (batch, spatial_size, num_heads, channels)
+ *   spatial_shapes (num_levels, 2) int64  [(H_l, W_l)]          -- device memory, read by the kernel
+ *   level_start    (num_levels,)   int64                         -- device memory, read by the kernel
+ *   sampling_loc   (batch, num_query, num_heads, num_levels, num_point, 2)   (x, y) in [0,1] coords
+ *   attn_weight    (batch, num_query, num_heads, num_levels, num_point)
+ *   out / grad_out (batch, num_query, num_heads * channels)
+ * Semantics: bilinear sampling with align_corners=False pixel mapping (h = y*H - 0.5), zero padding,
+ * a sample contributes only if -1 < h < H and -1 < w < W.  forward writes every element of `out`.
+ * backward zero-fills grad_value itself (hipMemsetAsync on `stream`), accumulates into it with fp
+ * atomics, and writes every element of grad_sampling_loc / grad_attn_weight.
+ * The whole batch is one launch (the reference's im2col_step chunking does not change results).
+ * f32: fast path for channels == 32, generic path otherwise.  f64: generic path (gradcheck parity).
+ * ------------------------------------------------------------------------------------------- */
+int semidetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                              const int64_t *level_start, const float *sampling_loc,
+                              const float *attn_weight, int batch, int spatial_size, int num_heads,
+                              int channels, int num_levels, int num_query, int num_point, float *out);
+int semidetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,
+                              const int64_t *level_start, const double *sampling_loc,
+                              const double *attn_weight, int batch, int spatial_size, int num_heads,
+                              int channels, int num_levels, int num_query, int num_point, double *out);
+int semidetr_msda_backward_f32(void *stream, const float *grad_out, const float *value,
+                               const int64_t *spatial_shapes, const int64_t *level_start,
+                               const float *sampling_loc, const float *attn_weight, int batch,
+                               int spatial_size, int num_heads, int channels, int num_levels,
+                               int num_query, int num_point, float *grad_value,
+                               float *grad_sampling_loc, float *grad_attn_weight);
+int semidetr_msda_backward_f64(void *stream, const double *grad_out, const double *value,
+                               const int64_t *spatial_shapes, const int64_t *level_start,
+                               const double *sampling_loc, const double *attn_weight, int batch,
+                               int spatial_size, int num_heads, int channels, int num_levels,
+                               int num_query, int num_point, double *grad_value,
+                               double *grad_sampling_loc, double *grad_attn_weight);
+
+/* Tuning knob for benchmarking the f32 / channels==32 fast path: variant 0 = automatic choice,
+ * >0 forces a kernel variant; process-wide, not thread-safe, tests leave it at 0. */
+void semidetr_msda_set_variant(int fwd_variant, int bwd_variant);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hungarian matcher: cost matrix + linear sum assignment + assignment scatter, batched and
+ * device-resident (no host round trip inside).
+ *
+ * Replaces  HungarianAssigner.assign   thirdparty/mmdetection/mmdet/core/bbox/assigners/hungarian_assigner.py:55-188
+ *           FocalLossCost/BBoxL1Cost/IoUCost.__call__  .../match_costs/match_cost.py:33-50,83-99,169-185
+ *           bbox_overlaps(giou|iou)    .../iou_calculators/iou2d_calculator.py:200-261
+ *           scipy.optimize.linear_sum_assignment (call sites hungarian_assigner.py:136,
+ *           detr_ssod/models/dino_detr_ssod.py:279) -- third-party scipy, pinned at 1.15.3
+ *           the inline twin of the above in DinoDetrSSOD.unsup_loss  detr_ssod/models/dino_detr_ssod.py:248-293
+ *
+ * A batch holds B independent problems; problem b has Q predictions (same Q for all) and
+ * G_b = gt_offsets[b+1] - gt_offsets[b] ground truths (ragged, G_b may be 0).
+ *   bbox_pred  (B, Q, 4) fp32  cx,cy,w,h normalised
+ *   cls_pred   (B, Q, C) fp32  logits
+ *   gt_bboxes  (sumG, 4) fp32  x1,y1,x2,y2 pixels ; gt_labels (sumG,) int64
+ *   gt_offsets (B+1,) int32 DEVICE ; img_wh (B, 2) fp32 DEVICE (img_w, img_h)
+ *   cost       (Q * sumG) fp32: problem b's matrix is TRANSPOSED-CONTIGUOUS, i.e. element (q, g) lives at
+ *              cost[Q*gt_offsets[b] + g*Q + q]  (a (G_b, Q) row-major block; the (Q, G_b) matrix the
+ *              reference builds is its transpose view).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct semidetr_cost_params {
+    float cls_weight;   /* FocalLossCost.weight  (DINO config: 2.0)  */
+    float alpha;        /* 0.25 */
+    float gamma;        /* 2.0  */
+    float eps;          /* 1e-12 */
+    float reg_weight;   /* BBoxL1Cost.weight (5.0) */
+    int   reg_xywh;     /* 1: box_format='xywh', 0: 'xyxy' */
+    float iou_weight;   /* IoUCost.weight (2.0) */
+    int   iou_giou;     /* 1: 'giou', 0: 'iou' */
+    int   pred_xyxy;    /* 0: bbox_pred is cx,cy,w,h (HungarianAssigner.assign); 1: it already is x1,y1,x2,y2
+                           (the stand-alone IoUCost.__call__ contract, match_cost.py:169-185) */
+} semidetr_cost_params;
+
+int semidetr_match_cost_f32(void *stream, const float *bbox_pred, const float *cls_pred,
+                            const float *gt_bboxes, const int64_t *gt_labels,
+                            const int32_t *gt_offsets, const float *img_wh, int num_problems,
+                            int num_query, int num_classes, int total_gt,
+                            const semidetr_cost_params *params /* host */, float *cost);
+
+/* Solve all B assignment problems on the device (one wavefront per problem), bit-exact with
+ * scipy.optimize.linear_sum_assignment on the same fp32 matrix (up-cast to fp64 as scipy does).
+ *   cost as laid out above.
+ *   match_row / match_col (sumK,) int64 with K_b = min(Q, G_b) pairs for problem b stored at
+ *       pair_offsets[b] = sum_{b'<b} min(Q, G_b')  -- because Q is shared this is computed on device
+ *       from gt_offsets; rows ascending (scipy's output order), cols = matched gt index in the problem.
+ *       Either may be NULL.
+ *   assigned_gt_inds / assigned_labels (B, Q) int64: hungarian_assigner.py:142-147 scatter
+ *       (0 / -1 for unmatched; when G_b == 0: gt_inds = 0, labels = -1). Either may be NULL.
+ *   status (B,) int32: 0 ok, 1 infeasible, 2 invalid numeric entries (NaN / -inf) -- scipy raises
+ *       ValueError for those; the host wrapper turns them into the same exception.
+ *   workspace: device scratch of semidetr_lsap_workspace_bytes(B, Q, maxG) bytes.
+ */
+int64_t semidetr_lsap_workspace_bytes(int num_problems, int num_query, int max_gt);
+int semidetr_lsap_solve(void *stream, const float *cost, const int32_t *gt_offsets,
+                        const int64_t *gt_labels, int num_problems, int num_query, int total_gt,
+                        int max_gt, int64_t *match_row, int64_t *match_col,
+                        int64_t *assigned_gt_inds, int64_t *assigned_labels, int32_t *status,
+                        void *workspace);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mean-teacher EMA, one launch for the whole parameter list.
+ *
+ * Replaces  MeanTeacher.momentum_update   detr_ssod/utils/hooks/mean_teacher.py:60-64
+ *           (tgt.mul_(m).add_(src, alpha=1-m) per parameter => ~1000 launches per step).
+ *   teacher_ptrs / student_ptrs (T,) device arrays of device pointers (float*), numels (T,) int64
+ *   device array, block_starts (T+1,) int32 device array = exclusive prefix sum of
+ *   ceil(numel / SEMIDETR_EMA_CHUNK) -- one workgroup processes one chunk.
+ *   Arithmetic per element: t = rn(t * (float)m); t = fma(s, (float)(1-m), t)   (torch's rounding).
+ * ------------------------------------------------------------------------------------------- */
+#define SEMIDETR_EMA_CHUNK 8192
+int semidetr_ema_multi_f32(void *stream, float *const *teacher_ptrs, const float *const *student_ptrs,
+                           const int64_t *numels, const int32_t *block_starts, int num_tensors,
+                           int total_blocks, double momentum);
+/* Same arithmetic on one flat arena (parameters laid out contiguously in HBM). */
+int semidetr_ema_flat_f32(void *stream, float *teacher, const float *student, int64_t numel,
+                          double momentum);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pseudo-label filter: per image mean+std score threshold, then drop empty boxes; one launch for
+ * the batch.
+ *
+ * Replaces  the per-image loop in DinoDetrSSOD.extract_teacher_info  detr_ssod/models/dino_detr_ssod.py:918-939
+ *   proposals (sumK, 5) fp32 x1,y1,x2,y2,score ; labels (sumK,) int64 ; prop_offsets (B+1,) int32 DEVICE
+ *   out_boxes (sumK,4), out_labels (sumK,), out_scores (sumK,): image b's kept entries are written
+ *   compacted, in the original order, starting at prop_offsets[b]; out_count (B,) int32 kept per image;
+ *   out_thr (B,) fp32 the threshold used (NaN for <2 proposals, as torch.std gives).
+ * ------------------------------------------------------------------------------------------- */
+int semidetr_pseudo_label_filter_f32(void *stream, const float *proposals, const int64_t *labels,
+                                     const int32_t *prop_offsets, int num_images, float *out_boxes,
+                                     int64_t *out_labels, float *out_scores, int32_t *out_keep_idx,
+                                     int32_t *out_count, float *out_thr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMIDETR_HIP_H */

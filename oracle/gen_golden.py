@@ -1,0 +1,352 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz from the REFERENCE's own Python, imported by path.
+
+Runs only in the build container (needs /root/reference, read-only).  The fixtures it writes are data
+(inputs + expected outputs); nothing of the reference's source travels.  Re-run:
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+What is imported from the reference (by file path, with stub registries for the absent mmcv/mmdet):
+  * detr_od/models/utils/ops/functions/ms_deform_attn_func.py  -> ms_deform_attn_core_pytorch (:41-61)
+    (forward oracle; backward oracle = torch.autograd through it)
+  * detr_od/models/utils/ops/modules/ms_deform_attn.py          -> MSDeformAttn (:30-126)
+  * thirdparty/mmdetection/mmdet/core/bbox/match_costs/match_cost.py (FocalLossCost, BBoxL1Cost, IoUCost)
+  * thirdparty/mmdetection/mmdet/core/bbox/iou_calculators/iou2d_calculator.py (bbox_overlaps)
+  * thirdparty/mmdetection/mmdet/core/bbox/transforms.py (cxcywh<->xyxy)
+The assignment itself comes from scipy.optimize.linear_sum_assignment (scipy 1.15.3), exactly as
+hungarian_assigner.py:136 calls it.  MeanTeacher / pseudo-label code needs mmcv to import, so those
+fixtures restate mean_teacher.py:46-64 and dino_detr_ssod.py:918-939 with the same torch calls.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _load(name, path, package=None):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    if package:
+        mod.__package__ = package
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_reference():
+    class _Registry:
+        def __init__(self, *a, **k):
+            pass
+
+        def register_module(self, *a, **k):
+            return lambda c: c
+
+    def _pkg(name):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+        return m
+
+    # --- op: stub the native module, then load functions + modules as a package "refops"
+    sys.modules["MultiScaleDeformableAttention"] = types.ModuleType("MultiScaleDeformableAttention")
+    ops = REF + "/detr_od/models/utils/ops"
+    _pkg("refops")
+    _pkg("refops.functions")
+    func = _load("refops.functions.ms_deform_attn_func", ops + "/functions/ms_deform_attn_func.py",
+                 "refops.functions")
+    sys.modules["refops.functions"].MSDeformAttnFunction = func.MSDeformAttnFunction
+    _pkg("refops.modules")
+    modl = _load("refops.modules.ms_deform_attn", ops + "/modules/ms_deform_attn.py", "refops.modules")
+
+    # --- matcher pieces
+    bb = REF + "/thirdparty/mmdetection/mmdet/core/bbox"
+    for n in ["mmdet", "mmdet.core", "mmdet.core.bbox", "mmdet.core.bbox.iou_calculators",
+              "mmdet.core.bbox.match_costs"]:
+        _pkg(n)
+    b = types.ModuleType("mmdet.core.bbox.iou_calculators.builder")
+    b.IOU_CALCULATORS = _Registry()
+    sys.modules[b.__name__] = b
+    iou = _load("mmdet.core.bbox.iou_calculators.iou2d_calculator",
+                bb + "/iou_calculators/iou2d_calculator.py", "mmdet.core.bbox.iou_calculators")
+    sys.modules["mmdet.core.bbox.iou_calculators"].bbox_overlaps = iou.bbox_overlaps
+    tr = _load("mmdet.core.bbox.transforms", bb + "/transforms.py", "mmdet.core.bbox")
+    b2 = types.ModuleType("mmdet.core.bbox.match_costs.builder")
+    b2.MATCH_COST = _Registry()
+    sys.modules[b2.__name__] = b2
+    mc = _load("mmdet.core.bbox.match_costs.match_cost", bb + "/match_costs/match_cost.py",
+               "mmdet.core.bbox.match_costs")
+    return func, modl, mc, tr, iou
+
+
+def level_start(shapes):
+    hw = [h * w for h, w in shapes]
+    return np.concatenate([[0], np.cumsum(hw)[:-1]]).astype(np.int64)
+
+
+def msda_case(func, name, shapes, N, M, D, Lq, P, dtype, seed, loc_mode="rand", gout_mode="rand"):
+    g = torch.Generator().manual_seed(seed)
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    value = torch.rand(N, S, M, D, generator=g) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    if loc_mode == "wide":          # well outside [0,1] on both sides, exercises the zero padding
+        loc = loc * 1.6 - 0.3
+    elif loc_mode == "edges":       # exact 0, 1, pixel centres, pixel edges, just outside
+        picks = []
+        for (h, w) in shapes:
+            xs = [0.0, 1.0, 0.5 / w, (w - 0.5) / w, 1.0 / w, -0.5 / w, (w + 0.5) / w, -1.0 / w, 0.5]
+            ys = [0.0, 1.0, 0.5 / h, (h - 0.5) / h, 1.0 / h, -0.5 / h, (h + 0.5) / h, -1.0 / h, 0.5]
+            picks.append((xs, ys))
+        for l, (xs, ys) in enumerate(picks):
+            ix = torch.randint(0, len(xs), (N, Lq, M, P), generator=g)
+            iy = torch.randint(0, len(ys), (N, Lq, M, P), generator=g)
+            loc[:, :, :, l, :, 0] = torch.tensor(xs)[ix]
+            loc[:, :, :, l, :, 1] = torch.tensor(ys)[iy]
+    attn = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
+    attn = attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    gout = torch.rand(N, Lq, M * D, generator=g) if gout_mode == "rand" else torch.ones(N, Lq, M * D)
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    value, loc, attn, gout = [t.to(tdt) for t in (value, loc, attn, gout)]
+    v, lo, a = [t.clone().requires_grad_(True) for t in (value, loc, attn)]
+    sh = torch.as_tensor(shapes, dtype=torch.long)
+    out = func.ms_deform_attn_core_pytorch(v, sh, lo, a)
+    out.backward(gout)
+    return {
+        f"{name}.shapes": np.asarray(shapes, np.int64), f"{name}.value": value.numpy(),
+        f"{name}.loc": loc.numpy(), f"{name}.attn": attn.numpy(), f"{name}.gout": gout.numpy(),
+        f"{name}.out": out.detach().numpy(), f"{name}.gvalue": v.grad.numpy(),
+        f"{name}.gloc": lo.grad.numpy(), f"{name}.gattn": a.grad.numpy(),
+    }
+
+
+def gen_msda(func):
+    d = {}
+    tiny = [(6, 4), (3, 2)]
+    # the reference's own test.py shapes (test.py:21-36), seed 3
+    d.update(msda_case(func, "testpy_f64", tiny, 1, 2, 2, 2, 2, "f64", 3))
+    d.update(msda_case(func, "testpy_f32", tiny, 1, 2, 2, 2, 2, "f32", 3))
+    # one D per backward dispatch branch of the reference (test.py:85-86) kept small enough to commit
+    for D in (4, 30, 32, 64, 71):
+        d.update(msda_case(func, f"tiny_D{D}_f64", tiny, 1, 2, D, 2, 2, "f64", 10 + D))
+    d.update(msda_case(func, "tiny_D1025_f64", [(3, 2), (1, 2)], 1, 1, 1025, 1, 2, "f64", 7))
+    # zero padding / boundary behaviour
+    d.update(msda_case(func, "wide_f64", [(5, 7), (3, 4), (1, 1)], 2, 3, 8, 11, 3, "f64", 21, "wide"))
+    d.update(msda_case(func, "edges_f64", [(4, 6), (1, 5), (3, 1), (2, 2)], 2, 2, 4, 9, 4, "f64", 22, "edges"))
+    d.update(msda_case(func, "edges_f32", [(4, 6), (1, 5), (3, 1), (2, 2)], 2, 2, 32, 9, 4, "f32", 23, "edges"))
+    # five levels (COCO-full variant), D=32 fast path
+    d.update(msda_case(func, "five_f32", [(7, 11), (4, 6), (3, 4), (2, 3), (1, 2)], 1, 8, 32, 13, 4, "f32", 24, "wide"))
+    # down-scaled DINO shape: 8 heads x 32 ch, 4 levels x 4 points
+    dino = [(9, 13), (5, 7), (3, 4), (2, 2)]
+    d.update(msda_case(func, "dino_f32", dino, 2, 8, 32, 21, 4, "f32", 25))
+    d.update(msda_case(func, "dino_f64", dino, 2, 8, 32, 21, 4, "f64", 25))
+    d.update(msda_case(func, "dino_ones_f32", dino, 2, 8, 32, 21, 4, "f32", 26, "wide", "ones"))
+    np.savez_compressed(os.path.join(OUT, "msda.npz"), **d)
+    return d
+
+
+def gen_module(modl, func):
+    """Pins MSDeformAttn.forward arithmetic around the op (modules/ms_deform_attn.py:78-126)."""
+    func.MSDeformAttnFunction.apply = staticmethod(
+        lambda v, sh, ls, loc, a, step: func.ms_deform_attn_core_pytorch(v, sh, loc, a))
+    d = {}
+    shapes = [(6, 8), (3, 4), (2, 2)]
+    sh = torch.as_tensor(shapes, dtype=torch.long)
+    ls = torch.as_tensor(level_start(shapes))
+    S = sum(h * w for h, w in shapes)
+    for name, refdim, use_mask in (("ref2", 2, False), ("ref4", 4, True)):
+        torch.manual_seed(5 + refdim)
+        m = modl.MSDeformAttn(d_model=32, n_levels=3, n_heads=4, n_points=2).double()
+        with torch.no_grad():   # the default init zeroes these; perturb so the fixture is informative
+            m.sampling_offsets.weight.normal_(0, 0.05)
+            m.attention_weights.weight.normal_(0, 0.2)
+            m.attention_weights.bias.normal_(0, 0.2)
+        N, Lq = 2, 7
+        query = torch.randn(N, Lq, 32, dtype=torch.float64)
+        src = torch.randn(N, S, 32, dtype=torch.float64)
+        ref = torch.rand(N, Lq, 3, refdim, dtype=torch.float64)
+        if refdim == 4:
+            ref[..., 2:] = ref[..., 2:] * 0.3 + 0.05
+        mask = (torch.rand(N, S) < 0.2) if use_mask else None
+        out = m(query, ref, src, sh, ls, mask)
+        for k, v in m.state_dict().items():
+            d[f"{name}.sd.{k}"] = v.numpy()
+        d[f"{name}.query"], d[f"{name}.src"], d[f"{name}.ref"] = query.numpy(), src.numpy(), ref.numpy()
+        d[f"{name}.shapes"] = np.asarray(shapes, np.int64)
+        if mask is not None:
+            d[f"{name}.mask"] = mask.numpy()
+        d[f"{name}.out"] = out.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "msda_module.npz"), **d)
+
+
+def ref_cost(mc, tr, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_w, img_h):
+    """hungarian_assigner.py:115-129 with the DINO config weights (dino_detr_r50_8x2_12e_coco.py:41-44)."""
+    cls_c = mc.FocalLossCost(weight=2.0)
+    reg_c = mc.BBoxL1Cost(weight=5.0, box_format="xywh")
+    iou_c = mc.IoUCost(iou_mode="giou", weight=2.0)
+    factor = gt_bboxes.new_tensor([img_w, img_h, img_w, img_h]).unsqueeze(0)
+    c1 = cls_c(cls_pred, gt_labels)
+    c2 = reg_c(bbox_pred, gt_bboxes / factor)
+    c3 = iou_c(tr.bbox_cxcywh_to_xyxy(bbox_pred) * factor, gt_bboxes)
+    return c1, c2, c3, c1 + c2 + c3
+
+
+def gen_cost(mc, tr):
+    d = {}
+    # the docstring known answer (match_cost.py:156-162)
+    iou = mc.IoUCost()(torch.FloatTensor([[1, 1, 2, 2], [2, 2, 3, 4]]),
+                       torch.FloatTensor([[0, 0, 2, 4], [1, 2, 3, 4]]))
+    d["doc_ioucost"] = iou.numpy()
+    cases = [(5, 3, 20), (300, 1, 80), (300, 7, 80), (900, 7, 80), (900, 30, 80), (900, 100, 80),
+             (17, 40, 20), (900, 0, 80), (12, 12, 5)]
+    names = []
+    for k, (Q, G, C) in enumerate(cases):
+        g = torch.Generator().manual_seed(100 + k)
+        img_w, img_h = (1333.0, 800.0) if k % 2 == 0 else (1201.0, 800.0)
+        cxcy = torch.rand(Q, 2, generator=g)
+        wh = torch.rand(Q, 2, generator=g) * 0.5 + 0.01
+        bbox_pred = torch.cat([cxcy, wh], -1)
+        cls_pred = torch.randn(Q, C, generator=g) * 3
+        xy1 = torch.rand(G, 2, generator=g) * torch.tensor([img_w, img_h]) * 0.8
+        gwh = torch.rand(G, 2, generator=g) * torch.tensor([img_w, img_h]) * 0.4 + 16
+        gt = torch.cat([xy1, torch.minimum(xy1 + gwh, torch.tensor([img_w, img_h]))], -1)
+        labels = torch.randint(0, C, (G,), generator=g)
+        if k == 0:      # degenerate boxes: zero-area prediction and zero-area gt (eps paths, iou2d:251-259)
+            bbox_pred[0, 2:] = 0
+            gt[0, 2:] = gt[0, :2]
+            bbox_pred[1] = torch.tensor([0.5, 0.5, 0.2, 0.2])      # identical pred pair -> tied rows
+            bbox_pred[2] = bbox_pred[1]
+            cls_pred[2] = cls_pred[1]
+        n = f"c{k}_Q{Q}_G{G}_C{C}"
+        names.append(n)
+        d[f"{n}.bbox_pred"], d[f"{n}.cls_pred"] = bbox_pred.numpy(), cls_pred.numpy()
+        d[f"{n}.gt_bboxes"], d[f"{n}.gt_labels"] = gt.numpy(), labels.numpy()
+        d[f"{n}.img_wh"] = np.asarray([img_w, img_h], np.float32)
+        gi = np.full(Q, -1, np.int64)
+        lab = np.full(Q, -1, np.int64)
+        if G == 0:
+            gi[:] = 0           # hungarian_assigner.py:108-114
+            rows = cols = np.zeros(0, np.int64)
+        else:
+            c1, c2, c3, c = ref_cost(mc, tr, bbox_pred, cls_pred, gt, labels, img_w, img_h)
+            if Q * G <= 900 * 7:
+                d[f"{n}.cost_cls"], d[f"{n}.cost_reg"], d[f"{n}.cost_iou"] = c1.numpy(), c2.numpy(), c3.numpy()
+            d[f"{n}.cost"] = c.numpy()
+            rows, cols = linear_sum_assignment(c)
+            gi[:] = 0
+            gi[rows] = cols + 1
+            lab[rows] = labels.numpy()[cols]
+        d[f"{n}.rows"], d[f"{n}.cols"] = rows.astype(np.int64), cols.astype(np.int64)
+        d[f"{n}.assigned_gt_inds"], d[f"{n}.assigned_labels"] = gi, lab
+    d["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(OUT, "cost.npz"), **d)
+
+
+def gen_lsap():
+    """Black-box pins of scipy 1.15.3 behaviour incl. ties, inf, rectangular shapes."""
+    d = {}
+    mats = {
+        "ones53": np.ones((5, 3)), "ones35": np.ones((3, 5)),
+        "tie_a": np.array([[1, 2], [1, 2], [1, 2], [0, 5.]]),
+        "tie_b": np.array([[1, 1], [1, 1], [0, 0.]]),
+        "inf_ok": np.array([[np.inf, 1], [2, np.inf], [3, 4]]),
+        "zeros77": np.zeros((7, 7)),
+    }
+    rng = np.random.default_rng(7)
+    for i in range(24):
+        nr, nc = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        kind = i % 4
+        if kind == 0:
+            c = rng.random((nr, nc))
+        elif kind == 1:
+            c = rng.integers(0, 3, (nr, nc)).astype(float)
+        elif kind == 2:
+            c = np.round(rng.random((nr, nc)) * 4) / 4
+            c[rng.random((nr, nc)) < 0.08] = np.inf
+        else:
+            c = rng.standard_normal((nr, nc)).astype(np.float32).astype(float)
+        mats[f"rnd{i}"] = c
+    names = []
+    for k, c in mats.items():
+        try:
+            r, cc = linear_sum_assignment(c)
+        except ValueError:
+            continue
+        names.append(k)
+        d[f"{k}.cost"], d[f"{k}.rows"], d[f"{k}.cols"] = c, r.astype(np.int64), cc.astype(np.int64)
+    d["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(OUT, "lsap.npz"), **d)
+
+
+def gen_ema():
+    """mean_teacher.py:46-48 (momentum schedule) and :60-64 (in-place update), via torch CPU."""
+    d = {}
+    steps = np.asarray([0, 1, 2, 3, 4, 5, 99, 100, 998, 999, 1000, 5000], np.int64)
+    for wu in (0, 100):
+        d[f"sched_wu{wu}"] = np.asarray(
+            [min(0.999, 1 - (1 + wu) / (int(s) + 1 + wu)) for s in steps], np.float64)
+    d["sched_steps"] = steps
+    g = torch.Generator().manual_seed(11)
+    shapes = [(16, 3, 7, 7), (64,), (48, 48), (1,), (17, 5), (100, 33)]
+    for mi, mom in enumerate((0.0, 0.5, 0.999, 0.9996)):
+        for si, shp in enumerate(shapes):
+            t = torch.randn(*shp, generator=g)
+            s = torch.randn(*shp, generator=g)
+            d[f"m{mi}.t{si}.teacher"], d[f"m{mi}.t{si}.student"] = t.numpy().copy(), s.numpy().copy()
+            t.mul_(mom).add_(s, alpha=1 - mom)
+            d[f"m{mi}.t{si}.out"] = t.numpy()
+        d[f"m{mi}.momentum"] = np.float64(mom)
+    np.savez_compressed(os.path.join(OUT, "ema.npz"), **d)
+
+
+def gen_pseudo():
+    """dino_detr_ssod.py:918-939 restated with the same torch calls."""
+    d = {}
+    g = torch.Generator().manual_seed(13)
+    names = []
+    for k, K in enumerate((300, 57, 2, 1, 0, 128)):
+        xy = torch.rand(K, 2, generator=g) * 800
+        wh = torch.rand(K, 2, generator=g) * 300 - (20 if k in (1, 5) else 0)   # some w/h <= 0
+        score = torch.rand(K, 1, generator=g) ** 3
+        box = torch.cat([xy, xy + wh, score], -1)
+        if K == 0:
+            box = box.new_zeros(0, 5)
+        lab = torch.randint(0, 80, (K,), generator=g)
+        if K > 0:
+            thr = torch.mean(box[:, -1]) + torch.std(box[:, -1])
+            valid = torch.nonzero(box[:, -1] >= thr, as_tuple=False).squeeze().unique()
+            tmp = box[valid, :4]
+            ok = ((tmp[:, 2] - tmp[:, 0]) > 0) & ((tmp[:, 3] - tmp[:, 1]) > 0)
+            valid = valid[ok]
+            thr = thr.numpy()
+        else:
+            valid, thr = torch.zeros(0, dtype=torch.long), np.float32("nan")
+        n = f"p{k}_K{K}"
+        names.append(n)
+        d[f"{n}.proposal"], d[f"{n}.labels"] = box.numpy(), lab.numpy()
+        d[f"{n}.keep"], d[f"{n}.thr"] = valid.numpy().astype(np.int64), np.float32(thr)
+    d["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(OUT, "pseudo.npz"), **d)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    func, modl, mc, tr, _ = import_reference()
+    gen_msda(func)
+    gen_module(modl, func)
+    gen_cost(mc, tr)
+    gen_lsap()
+    gen_ema()
+    gen_pseudo()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

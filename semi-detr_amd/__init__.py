@@ -1,0 +1,27 @@
+"""semi-detr_amd: MI355X (gfx950) native hot path of Semi-DETR / DINO-DETR.
+
+Scope: multi-scale deformable attention forward/backward, the Hungarian matcher
+(cost matrix + LSAP + scatter), the mean-teacher EMA update and the pseudo-label filter, plus the
+image-sharded data-parallel wrapper.  Host side is Python mirroring the reference's operator/plugin
+surface; all arithmetic runs in hand-written HIP kernels behind the C ABI of
+``include/semidetr_hip.h`` (``csrc/libsemidetr_hip.so``).  There is no CPU fallback.
+"""
+import sys as _sys
+
+from . import _lib  # noqa: F401
+from . import MultiScaleDeformableAttention as _msda_native
+
+# The reference does `import MultiScaleDeformableAttention as MSDA`
+# (detr_od/models/utils/ops/functions/ms_deform_attn_func.py:18); make that import resolve to ours.
+_sys.modules.setdefault("MultiScaleDeformableAttention", _msda_native)
+
+from .ops.functions import MSDeformAttnFunction  # noqa: E402,F401
+from .ops.modules import MSDeformAttn  # noqa: E402,F401
+from .matcher import (AssignResult, BBoxL1Cost, FocalLossCost, HungarianAssigner, IoUCost,  # noqa: E402,F401
+                      linear_sum_assignment)
+from .mean_teacher import MeanTeacher, ema_momentum, ema_update_, ema_update_flat_  # noqa: E402,F401
+from .pseudo_label import filter_pseudo_labels  # noqa: E402,F401
+
+__all__ = ["MSDeformAttnFunction", "MSDeformAttn", "HungarianAssigner", "FocalLossCost", "BBoxL1Cost",
+           "IoUCost", "AssignResult", "linear_sum_assignment", "MeanTeacher", "ema_momentum", "ema_update_",
+           "ema_update_flat_", "filter_pseudo_labels"]

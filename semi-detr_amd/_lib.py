@@ -1,0 +1,74 @@
+"""ctypes binding of ``libsemidetr_hip.so`` (C ABI declared in ``include/semidetr_hip.h``).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.  The
+library is built in-tree by ``__graft_entry__.build()`` / ``make -C semi-detr_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsemidetr_hip.so")
+
+c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+
+
+class CostParams(ctypes.Structure):
+    """Mirror of ``semidetr_cost_params`` (include/semidetr_hip.h)."""
+    _fields_ = [("cls_weight", ctypes.c_float), ("alpha", ctypes.c_float), ("gamma", ctypes.c_float),
+                ("eps", ctypes.c_float), ("reg_weight", ctypes.c_float), ("reg_xywh", ctypes.c_int),
+                ("iou_weight", ctypes.c_float), ("iou_giou", ctypes.c_int), ("pred_xyxy", ctypes.c_int)]
+
+
+_MSDA_FWD = [c_void_p] * 6 + [c_int] * 7 + [c_void_p]
+_MSDA_BWD = [c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 3
+
+# name -> (restype, argtypes); must list every function include/semidetr_hip.h declares
+SIGNATURES = {
+    "semidetr_abi_version": (c_int, []),
+    "semidetr_last_error": (ctypes.c_char_p, []),
+    "semidetr_msda_forward_f32": (c_int, _MSDA_FWD),
+    "semidetr_msda_forward_f64": (c_int, _MSDA_FWD),
+    "semidetr_msda_backward_f32": (c_int, _MSDA_BWD),
+    "semidetr_msda_backward_f64": (c_int, _MSDA_BWD),
+    "semidetr_msda_set_variant": (None, [c_int, c_int]),
+    "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
+    "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "semidetr_lsap_solve": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 6),
+    "semidetr_ema_multi_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_double]),
+    "semidetr_ema_flat_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_double]),
+    "semidetr_pseudo_label_filter_f32": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 6),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  Raises ``NativeLibraryError`` when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C semi-detr_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError if the .so is stale / symbol missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    """Turn a C-ABI status into a RuntimeError (what the reference's AT_ASSERTM / launch failures give)."""
+    if rc != 0:
+        msg = lib().semidetr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def current_stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,240 @@
+// Device-resident rectangular linear-sum-assignment for gfx950, bit-exact with
+// scipy.optimize.linear_sum_assignment (scipy 1.15.3; the solver the reference calls at
+// thirdparty/mmdetection/mmdet/core/bbox/assigners/hungarian_assigner.py:136 and
+// detr_ssod/models/dino_detr_ssod.py:279), followed by the assignment scatter of
+// hungarian_assigner.py:142-147.
+//
+// Why on the device: the reference copies every cost matrix to the host (`cost.detach().cpu()`,
+// hungarian_assigner.py:132 -- a blocking sync), solves it in scipy and copies indices back; a Semi-DETR
+// step does that ~39 times.  Here all problems of a loss() call are solved in ONE launch, one 64-lane
+// wavefront per problem, with every solver array in LDS; nothing leaves HBM.
+//
+// Algorithm (published: Crouse 2016, shortest augmenting paths with dual variables; restated in
+// oracle/lsap_oracle.c).  The sequential inner scan over the not-yet-scanned columns becomes a
+// wavefront-parallel scan + a lexicographic wave reduction that reproduces scipy's tie rule exactly:
+// among the columns with the minimal reduced cost pick the LAST unassigned one in list order if there is
+// any, otherwise the FIRST one in list order.  The list ("remaining") is kept in scipy's order
+// (descending initialisation, swap-with-last removal) so ties resolve identically.  fp64 arithmetic,
+// contraction off, same expression order => identical comparisons => identical indices.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr double kInf = __builtin_huge_val();
+
+struct Best {
+    double low;
+    int first;     // first list position attaining `low`
+    int last_un;   // last list position attaining `low` whose column is unassigned, or -1
+};
+
+__device__ __forceinline__ Best combine(const Best &a, const Best &b)
+{
+    if (b.low < a.low) return b;
+    if (a.low < b.low) return a;
+    Best r = a;
+    r.first = min(a.first, b.first);
+    r.last_un = max(a.last_un, b.last_un);
+    return r;
+}
+
+__device__ __forceinline__ Best wave_best(Best x)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        Best o;
+        o.low = __shfl_xor(x.low, s, 64);
+        o.first = __shfl_xor(x.first, s, 64);
+        o.last_un = __shfl_xor(x.last_un, s, 64);
+        x = combine(x, o);
+    }
+    return x;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t lsap_bytes(int ncmax, int nrmax)
+{
+    return align16((size_t)ncmax * 8) * 2 + align16((size_t)nrmax * 8) + align16((size_t)ncmax * 4) * 3 +
+           align16((size_t)nrmax * 4) + align16((size_t)(nrmax + 1) * 4);
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(64) void lsap_kernel(
+    const float *__restrict__ cost, const int32_t *__restrict__ gt_offsets,
+    const int64_t *__restrict__ gt_labels, int Q, int ncmax, int nrmax, int64_t *__restrict__ match_row,
+    int64_t *__restrict__ match_col, int64_t *__restrict__ gt_inds, int64_t *__restrict__ labels,
+    int32_t *__restrict__ status, char *__restrict__ ws, size_t ws_stride)
+{
+    extern __shared__ double smem_d[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int g0 = gt_offsets[b], G = gt_offsets[b + 1] - g0;
+
+    // defaults of the scatter: every prediction background (hungarian_assigner.py:142 / :108-114)
+    for (int q = lane; q < Q; q += 64) {
+        if (gt_inds) gt_inds[(int64_t)b * Q + q] = 0;
+        if (labels) labels[(int64_t)b * Q + q] = -1;
+    }
+    if (lane == 0) status[b] = 0;
+    if (G <= 0 || Q <= 0) return;
+
+    int po = 0;   // where this problem's (row, col) pairs start
+    for (int bb = lane; bb < b; bb += 64) po += min(Q, gt_offsets[bb + 1] - gt_offsets[bb]);
+    po = wave_sum_i(po);
+
+    const bool tr = G < Q;                        // scipy solves the transposed problem when nc < nr
+    const int nr = tr ? G : Q, nc = tr ? Q : G;
+    const float *cb = cost + (int64_t)Q * g0;     // (G, Q) row-major block, element (q, g) at cb[g*Q + q]
+    const int64_t si = tr ? Q : 1, sj = tr ? 1 : Q;   // solver (i, j) -> cb[i*si + j*sj]
+
+    char *base = USE_LDS ? reinterpret_cast<char *>(smem_d) : ws + (size_t)b * ws_stride;
+    double *v = reinterpret_cast<double *>(base);       base += align16((size_t)ncmax * 8);
+    double *spc = reinterpret_cast<double *>(base);     base += align16((size_t)ncmax * 8);
+    double *u = reinterpret_cast<double *>(base);       base += align16((size_t)nrmax * 8);
+    int *path = reinterpret_cast<int *>(base);          base += align16((size_t)ncmax * 4);
+    int *row4col = reinterpret_cast<int *>(base);       base += align16((size_t)ncmax * 4);
+    int *remaining = reinterpret_cast<int *>(base);     base += align16((size_t)ncmax * 4);
+    int *col4row = reinterpret_cast<int *>(base);       base += align16((size_t)nrmax * 4);
+    int *scanned = reinterpret_cast<int *>(base);
+
+    // scipy rejects NaN and -inf up front ("matrix contains invalid numeric entries")
+    int bad = 0;
+    for (int64_t k = lane; k < (int64_t)nr * nc; k += 64) {
+        const float c = cb[k];
+        if (c != c || c == -__builtin_huge_valf()) bad = 1;
+    }
+    if (__any(bad)) {
+        if (lane == 0) status[b] = 2;
+        return;
+    }
+
+    for (int j = lane; j < nc; j += 64) { v[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+    __syncthreads();
+
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int j = lane; j < nc; j += 64) { spc[j] = kInf; remaining[j] = nc - j - 1; }
+        __syncthreads();
+        int num_rem = nc, ns = 0, sink = -1, i = cur;
+        double min_val = 0.0;
+        while (sink == -1) {
+            const double ui = u[i];
+            const float *crow = cb + (int64_t)i * si;
+            Best best = {kInf, 0x7fffffff, -1};
+            for (int it = lane; it < num_rem; it += 64) {
+                const int j = remaining[it];
+                const double r = min_val + (double)crow[(int64_t)j * sj] - ui - v[j];
+                double s = spc[j];
+                if (r < s) { path[j] = i; spc[j] = r; s = r; }
+                const bool un = row4col[j] == -1;
+                if (s < best.low) { best.low = s; best.first = it; best.last_un = un ? it : -1; }
+                else if (s == best.low && un) best.last_un = it;
+            }
+            best = wave_best(best);
+            min_val = best.low;
+            if (min_val == kInf) {                 // "cost matrix is infeasible"
+                if (lane == 0) status[b] = 1;
+                return;
+            }
+            const int idx = best.last_un >= 0 ? best.last_un : best.first;
+            const int j = remaining[idx];
+            const int r4c = row4col[j];
+            __syncthreads();
+            if (lane == 0) { scanned[ns] = j; remaining[idx] = remaining[num_rem - 1]; }
+            ++ns; --num_rem;
+            if (r4c == -1) sink = j; else i = r4c;
+            __syncthreads();
+        }
+        // dual update: rows / columns touched by this search are exactly the scanned columns
+        if (lane == 0) u[cur] += min_val;
+        for (int t = lane; t < ns; t += 64) {
+            const int j = scanned[t];
+            const double d = min_val - spc[j];
+            if (j != sink) u[row4col[j]] += d;
+            v[j] -= d;
+        }
+        __syncthreads();
+        if (lane == 0) {                           // augment along the alternating path
+            int j = sink;
+            for (;;) {
+                const int ii = path[j];
+                row4col[j] = ii;
+                const int t = col4row[ii];
+                col4row[ii] = j;
+                j = t;
+                if (ii == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+
+    // pairs in scipy's output order (rows ascending) + hungarian_assigner.py:142-147 scatter
+    for (int i = lane; i < nr; i += 64) {
+        const int c = col4row[i];
+        int q, g, rank;
+        if (tr) {
+            q = c; g = i; rank = 0;
+            for (int k = 0; k < nr; ++k) rank += col4row[k] < c;
+        } else {
+            q = i; g = c; rank = i;
+        }
+        if (match_row) match_row[po + rank] = q;
+        if (match_col) match_col[po + rank] = g;
+        if (gt_inds) gt_inds[(int64_t)b * Q + q] = g + 1;
+        if (labels) labels[(int64_t)b * Q + q] = gt_labels[g0 + g];
+    }
+}
+
+constexpr size_t kLdsLimit = 64 * 1024;
+
+}  // namespace
+
+extern "C" int64_t semidetr_lsap_workspace_bytes(int num_problems, int num_query, int max_gt)
+{
+    if (num_problems <= 0 || num_query <= 0 || max_gt <= 0) return 0;
+    const int ncmax = num_query > max_gt ? num_query : max_gt;
+    const int nrmax = num_query < max_gt ? num_query : max_gt;
+    const size_t per = lsap_bytes(ncmax, nrmax);
+    return per <= kLdsLimit ? 0 : (int64_t)(per * (size_t)num_problems);
+}
+
+extern "C" int semidetr_lsap_solve(void *stream, const float *cost, const int32_t *gt_offsets,
+                                   const int64_t *gt_labels, int num_problems, int num_query, int total_gt,
+                                   int max_gt, int64_t *match_row, int64_t *match_col,
+                                   int64_t *assigned_gt_inds, int64_t *assigned_labels, int32_t *status,
+                                   void *workspace)
+{
+    SEMIDETR_REQUIRE(num_problems >= 0 && num_query >= 0 && total_gt >= 0 && max_gt >= 0 && max_gt <= total_gt,
+                     SEMIDETR_E_BADARG, "lsap: bad sizes (B=%d Q=%d sumG=%d maxG=%d)", num_problems, num_query,
+                     total_gt, max_gt);
+    if (num_problems == 0) return SEMIDETR_OK;
+    SEMIDETR_REQUIRE(gt_offsets && status, SEMIDETR_E_BADARG, "lsap: null gt_offsets/status");
+    SEMIDETR_REQUIRE(total_gt == 0 || num_query == 0 || cost, SEMIDETR_E_BADARG, "lsap: null cost");
+    SEMIDETR_REQUIRE(!assigned_labels || total_gt == 0 || gt_labels, SEMIDETR_E_BADARG, "lsap: null gt_labels");
+    const int ncmax = num_query > max_gt ? num_query : max_gt;
+    const int nrmax = num_query < max_gt ? num_query : max_gt;
+    const size_t per = lsap_bytes(ncmax > 0 ? ncmax : 1, nrmax > 0 ? nrmax : 1);
+    hipStream_t st = semidetr::as_stream(stream);
+    if (per <= kLdsLimit) {
+        hipLaunchKernelGGL(lsap_kernel<true>, dim3(num_problems), dim3(64), per, st, cost, gt_offsets,
+                           gt_labels, num_query, ncmax, nrmax, match_row, match_col, assigned_gt_inds,
+                           assigned_labels, status, (char *)nullptr, (size_t)0);
+    } else {
+        SEMIDETR_REQUIRE(workspace, SEMIDETR_E_BADARG, "lsap: workspace of %lld bytes required",
+                         (long long)(per * (size_t)num_problems));
+        hipLaunchKernelGGL(lsap_kernel<false>, dim3(num_problems), dim3(64), 0, st, cost, gt_offsets,
+                           gt_labels, num_query, ncmax, nrmax, match_row, match_col, assigned_gt_inds,
+                           assigned_labels, status, (char *)workspace, per);
+    }
+    return semidetr::launch_status("lsap_kernel");
+}

@@ -1,0 +1,564 @@
+// Multi-scale deformable attention for gfx950 (MI355X, CDNA4): forward + backward.
+//
+// Behavioural spec = the reference CUDA op (detr_od/models/utils/ops/src/cuda/ms_deform_im2col_cuda.cuh:
+// forward :237-299 with bilinear fetch :33-84; backward :301-403 with scatter :87-159), re-designed
+// for 64-wide wavefronts -- not a translation:
+//
+//  * D == 32 / fp32 fast path (the DINO-DETR shape): one 256-thread workgroup owns a tile of queries
+//    of ONE (batch, head).  Consecutive workgroups walk the heads, so with the observed block->XCD
+//    round-robin every XCD's private 4 MiB L2 only ever holds value rows of "its" heads
+//    (one head of one image = S*128 B = 2.8 MB at 800x1333).  Phase 1: the tile's sampling locations /
+//    attention weights are read once with coalesced loads and turned into per-sample records
+//    {4 corner offsets, 4 weights} in LDS (the reference recomputes them in all 32 channel threads and
+//    re-reads the int64 level table from global per sample).  Phase 2: 8 lanes x float4 cover one
+//    128-byte value row per corner, so each global_load_dwordx4 wave-instruction moves 8 full cache
+//    lines; the channel reduction of the backward pass is 3 DPP steps inside the 8-lane group instead
+//    of shared memory + barriers + a serial thread-0 loop; grad_sampling_loc / grad_attn_weight are
+//    staged in LDS and written back coalesced.
+//  * generic path (any D, fp32/fp64): one wavefront per (n, q, m) row, lanes stride the channels.
+//
+// Coordinates are computed WITHOUT fma contraction so cell selection (floor) is bit-identical to the
+// CPU oracle; everything downstream may contract.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxLevels = 32;
+
+// ---------------------------------------------------------------------------------------------
+// sample geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 corner validity)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+
+// off[i] = element offset of corner i relative to (value + n*S*M*D + m*D), or -1 when the corner is
+// outside the level (zero padding).  Returns false when the whole sample is skipped.
+template <typename T>
+__device__ __forceinline__ bool sample_setup(T x, T y, int H, int W, int start, int rowstride,
+                                             int (&off)[4], T &lw, T &lh)
+{
+    const T h = sub_rn(mul_rn(y, (T)H), (T)0.5);
+    const T w = sub_rn(mul_rn(x, (T)W), (T)0.5);
+    off[0] = off[1] = off[2] = off[3] = -1;
+    lw = lh = 0;
+    if (!(h > (T)-1 && w > (T)-1 && h < (T)H && w < (T)W)) return false;
+    const int h0 = (int)floor(h), w0 = (int)floor(w);
+    lh = sub_rn(h, (T)h0);
+    lw = sub_rn(w, (T)w0);
+    const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
+    const int base = (start + h0 * W + w0) * rowstride;
+    if (top && lef) off[0] = base;
+    if (top && rig) off[1] = base + rowstride;
+    if (bot && lef) off[2] = base + W * rowstride;
+    if (bot && rig) off[3] = base + (W + 1) * rowstride;
+    return true;
+}
+
+__device__ __forceinline__ void fp_atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void fp_atomic_add(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic path: one wavefront per (n, q, m) row
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void msda_fwd_generic(
+    const T *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const T *__restrict__ loc, const T *__restrict__ attn, int N, int S, int M, int D, int L, int Lq,
+    int P, T *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= (int64_t)N * Lq * M) return;
+    const int m = (int)(row % M);
+    const int n = (int)(row / ((int64_t)M * Lq));
+    const T *vb = value + ((int64_t)n * S * M + m) * D;
+    const T *lrow = loc + row * L * P * 2;
+    const T *arow = attn + row * L * P;
+    const int rs = M * D;
+    for (int c0 = 0; c0 < D; c0 += 64) {
+        const int c = c0 + lane;
+        const bool act = c < D;
+        T acc = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            for (int p = 0; p < P; ++p) {
+                int off[4];
+                T lw, lh;
+                const T x = lrow[(l * P + p) * 2], y = lrow[(l * P + p) * 2 + 1];
+                if (!sample_setup(x, y, H, W, st, rs, off, lw, lh)) continue;
+                const T a = arow[l * P + p];
+                const T hh = 1 - lh, hw = 1 - lw;
+                if (act) {
+                    const T v1 = off[0] >= 0 ? vb[off[0] + c] : (T)0;
+                    const T v2 = off[1] >= 0 ? vb[off[1] + c] : (T)0;
+                    const T v3 = off[2] >= 0 ? vb[off[2] + c] : (T)0;
+                    const T v4 = off[3] >= 0 ? vb[off[3] + c] : (T)0;
+                    acc += a * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
+                }
+            }
+        }
+        if (act) out[row * D + c] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void msda_bwd_generic(
+    const T *__restrict__ gout, const T *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const T *__restrict__ loc, const T *__restrict__ attn, int N,
+    int S, int M, int D, int L, int Lq, int P, T *__restrict__ gvalue, T *__restrict__ gloc,
+    T *__restrict__ gattn)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= (int64_t)N * Lq * M) return;
+    const int m = (int)(row % M);
+    const int n = (int)(row / ((int64_t)M * Lq));
+    const int64_t vo = ((int64_t)n * S * M + m) * D;
+    const T *vb = value + vo;
+    T *gvb = gvalue + vo;
+    const T *lrow = loc + row * L * P * 2;
+    const T *arow = attn + row * L * P;
+    const T *grow = gout + row * D;
+    const int rs = M * D;
+    for (int l = 0; l < L; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+        for (int p = 0; p < P; ++p) {
+            int off[4];
+            T lw, lh;
+            const T x = lrow[(l * P + p) * 2], y = lrow[(l * P + p) * 2 + 1];
+            const bool inside = sample_setup(x, y, H, W, st, rs, off, lw, lh);
+            T s_attn = 0, s_x = 0, s_y = 0;
+            if (inside) {
+                const T a = arow[l * P + p];
+                const T hh = 1 - lh, hw = 1 - lw;
+                const T w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+                for (int c = lane; c < D; c += 64) {
+                    const T g = grow[c], ga = g * a;
+                    T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+                    if (off[0] >= 0) { v1 = vb[off[0] + c]; fp_atomic_add(gvb + off[0] + c, w1 * ga); }
+                    if (off[1] >= 0) { v2 = vb[off[1] + c]; fp_atomic_add(gvb + off[1] + c, w2 * ga); }
+                    if (off[2] >= 0) { v3 = vb[off[2] + c]; fp_atomic_add(gvb + off[2] + c, w3 * ga); }
+                    if (off[3] >= 0) { v4 = vb[off[3] + c]; fp_atomic_add(gvb + off[3] + c, w4 * ga); }
+                    s_attn += g * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+                    s_x += ga * (hh * (v2 - v1) + lh * (v4 - v3));
+                    s_y += ga * (hw * (v3 - v1) + lw * (v4 - v2));
+                }
+                s_attn = wave_sum(s_attn);
+                s_x = wave_sum(s_x);
+                s_y = wave_sum(s_y);
+            }
+            if (lane == 0) {
+                const int64_t k = row * L * P + l * P + p;
+                gattn[k] = s_attn;
+                gloc[2 * k] = (T)W * s_x;
+                gloc[2 * k + 1] = (T)H * s_y;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast path: fp32, D == 32.  8 lanes x float4 per 128-byte value row.
+// ---------------------------------------------------------------------------------------------
+constexpr int kD = 32;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// sum over the 8 lanes of a group: quad xor1, quad xor2, then mirror inside the half-row (i <-> 7-i).
+__device__ __forceinline__ float group8_sum(float x)
+{
+    x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);  // row_half_mirror
+    return x;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p, int off)
+{
+    return off >= 0 ? *reinterpret_cast<const float4 *>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Workgroup -> (n, query tile, m): m fastest so that blockIdx % 8 == m % 8 when M % 8 == 0 (L2 affinity,
+// speed only -- correctness never depends on placement).
+struct Tile {
+    int n, q0, m;
+};
+__device__ __forceinline__ Tile tile_of_block(int M, int tiles_per_image, int rows_per_block)
+{
+    const int b = blockIdx.x;
+    Tile t;
+    t.m = b % M;
+    const int r = b / M;
+    t.q0 = (r % tiles_per_image) * rows_per_block;
+    t.n = r / tiles_per_image;
+    return t;
+}
+
+// SPLIT = number of 8-lane groups that share one (q) row; each takes samples k = part, part+SPLIT, ...
+template <int SPLIT>
+__global__ __launch_bounds__(256) void msda_fwd_d32(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq, int P,
+    int tiles_per_image, float *__restrict__ out)
+{
+    constexpr int RPB = 32 / SPLIT;   // query rows per workgroup
+    extern __shared__ float4 smem[];
+    const int LP = L * P, LPP = LP + 1;   // +1 record of padding: rows land on different LDS banks
+    int4 *rec_off = reinterpret_cast<int4 *>(smem);
+    float4 *rec_w = smem + RPB * LPP;
+
+    const Tile t = tile_of_block(M, tiles_per_image, RPB);
+    const int rs = M * kD;
+
+    // ---- phase 1: sample records -------------------------------------------------------------
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int r = s / LP, k = s - r * LP;
+        const int q = t.q0 + r;
+        int off[4] = {-1, -1, -1, -1};
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < Lq) {
+            const int l = k / P;
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
+            float lw, lh;
+            if (sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh)) {
+                const float a = attn[row * LP + k];
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                w = make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw));
+            }
+        }
+        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_w[r * LPP + k] = w;
+    }
+    __syncthreads();
+
+    // ---- phase 2: gather + weighted sum ------------------------------------------------------
+    const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int r = g / SPLIT, part = g % SPLIT;
+    const int q = t.q0 + r;
+    const float *vb = value + ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int4 *ro = rec_off + r * LPP;
+    const float4 *rw = rec_w + r * LPP;
+#pragma unroll 4
+    for (int k = part; k < LP; k += SPLIT) {
+        const int4 o = ro[k];
+        const float4 w = rw[k];
+        const float4 v1 = ld4(vb, o.x), v2 = ld4(vb, o.y), v3 = ld4(vb, o.z), v4 = ld4(vb, o.w);
+        acc.x += w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
+        acc.y += w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
+        acc.z += w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
+        acc.w += w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
+    }
+    if (SPLIT > 1) {
+#pragma unroll
+        for (int s = 8; s < 8 * SPLIT; s <<= 1) {
+            acc.x += __shfl_xor(acc.x, s, 64);
+            acc.y += __shfl_xor(acc.y, s, 64);
+            acc.z += __shfl_xor(acc.z, s, 64);
+            acc.w += __shfl_xor(acc.w, s, 64);
+        }
+    }
+    if (part == 0 && q < Lq) {
+        const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
+        *reinterpret_cast<float4 *>(out + row * kD + 4 * j) = acc;
+    }
+}
+
+template <int SPLIT>
+__global__ __launch_bounds__(256) void msda_bwd_d32(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn,
+    int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ gvalue,
+    float *__restrict__ gloc, float *__restrict__ gattn)
+{
+    constexpr int RPB = 32 / SPLIT;
+    extern __shared__ float4 smem[];
+    const int LP = L * P, LPP = LP + 1;
+    int4 *rec_off = reinterpret_cast<int4 *>(smem);
+    float4 *rec_p = smem + RPB * LPP;   // {lw, lh, a, level} ; overwritten with {g_attn, g_x, g_y, -}
+    float *lev_w = reinterpret_cast<float *>(smem + 2 * RPB * LPP), *lev_h = lev_w + kMaxLevels;
+
+    const Tile t = tile_of_block(M, tiles_per_image, RPB);
+    const int rs = M * kD;
+    if (threadIdx.x < L) {
+        lev_h[threadIdx.x] = (float)shapes[2 * threadIdx.x];
+        lev_w[threadIdx.x] = (float)shapes[2 * threadIdx.x + 1];
+    }
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int r = s / LP, k = s - r * LP;
+        const int q = t.q0 + r;
+        int off[4] = {-1, -1, -1, -1};
+        const int l = k / P;
+        float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
+        if (q < Lq) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
+            float lw, lh;
+            if (sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh)) {
+                pr.x = lw;
+                pr.y = lh;
+                pr.z = attn[row * LP + k];
+            }
+        }
+        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_p[r * LPP + k] = pr;
+    }
+    __syncthreads();
+
+    const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int r = g / SPLIT, part = g % SPLIT;
+    const int q = t.q0 + r;
+    const int64_t vo = ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
+    const float *vb = value + vo;
+    float *gvb = gvalue + vo;
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Lq) {
+        const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
+        go = *reinterpret_cast<const float4 *>(gout + row * kD + 4 * j);
+    }
+    const int4 *ro = rec_off + r * LPP;
+    float4 *rp = rec_p + r * LPP;
+#pragma unroll 2
+    for (int k = part; k < LP; k += SPLIT) {
+        const int4 o = ro[k];
+        const float4 pr = rp[k];
+        const float lw = pr.x, lh = pr.y, a = pr.z;
+        const int l = __float_as_int(pr.w);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const float4 v1 = ld4(vb, o.x), v2 = ld4(vb, o.y), v3 = ld4(vb, o.z), v4 = ld4(vb, o.w);
+        const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
+        if (o.x >= 0) {
+            float *p = gvb + o.x;
+            fp_atomic_add(p, w1 * ga.x); fp_atomic_add(p + 1, w1 * ga.y);
+            fp_atomic_add(p + 2, w1 * ga.z); fp_atomic_add(p + 3, w1 * ga.w);
+        }
+        if (o.y >= 0) {
+            float *p = gvb + o.y;
+            fp_atomic_add(p, w2 * ga.x); fp_atomic_add(p + 1, w2 * ga.y);
+            fp_atomic_add(p + 2, w2 * ga.z); fp_atomic_add(p + 3, w2 * ga.w);
+        }
+        if (o.z >= 0) {
+            float *p = gvb + o.z;
+            fp_atomic_add(p, w3 * ga.x); fp_atomic_add(p + 1, w3 * ga.y);
+            fp_atomic_add(p + 2, w3 * ga.z); fp_atomic_add(p + 3, w3 * ga.w);
+        }
+        if (o.w >= 0) {
+            float *p = gvb + o.w;
+            fp_atomic_add(p, w4 * ga.x); fp_atomic_add(p + 1, w4 * ga.y);
+            fp_atomic_add(p + 2, w4 * ga.z); fp_atomic_add(p + 3, w4 * ga.w);
+        }
+        // per-lane partials over its 4 channels, then the 8-lane group sum
+        float pa = go.x * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) +
+                   go.y * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) +
+                   go.z * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) +
+                   go.w * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
+        float px = ga.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) +
+                   ga.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
+                   ga.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) +
+                   ga.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
+        float py = ga.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) +
+                   ga.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
+                   ga.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) +
+                   ga.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
+        pa = group8_sum(pa);
+        px = group8_sum(px);
+        py = group8_sum(py);
+        if (j == 0) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, 0.f);
+    }
+    __syncthreads();
+
+    // ---- coalesced write-back of grad_attn_weight / grad_sampling_loc --------------------------
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int rr = s / LP, k = s - rr * LP;
+        const int qq = t.q0 + rr;
+        if (qq >= Lq) continue;
+        const int64_t row = ((int64_t)t.n * Lq + qq) * M + t.m;
+        const float4 res = rec_p[rr * LPP + k];
+        gattn[row * LP + k] = res.x;
+        *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
+    }
+}
+
+int g_fwd_variant = 0, g_bwd_variant = 0;
+
+int check_common(const void *value, const void *shapes, const void *starts, const void *loc,
+                 const void *attn, int N, int S, int M, int D, int L, int Lq, int P, size_t elem)
+{
+    SEMIDETR_REQUIRE(value && shapes && starts && loc && attn, SEMIDETR_E_BADARG, "msda: null pointer argument");
+    SEMIDETR_REQUIRE(N > 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq > 0 && P > 0, SEMIDETR_E_BADARG,
+                     "msda: sizes must be positive (N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d)", N, S, M, D, L, Lq, P);
+    // device index arithmetic inside one image is 32-bit (as in the reference, .cuh:255-269)
+    SEMIDETR_REQUIRE((int64_t)(S + 1) * M * D < INT32_MAX, SEMIDETR_E_TOOLARGE,
+                     "msda: spatial_size*num_heads*channels = %lld exceeds 32-bit indexing", (long long)S * M * D);
+    SEMIDETR_REQUIRE((int64_t)N * Lq * M < INT32_MAX / 4, SEMIDETR_E_TOOLARGE, "msda: too many (n,q,m) rows");
+    (void)elem;
+    return SEMIDETR_OK;
+}
+
+template <typename T>
+int forward_impl(void *stream, const T *value, const int64_t *shapes, const int64_t *starts, const T *loc,
+                 const T *attn, int N, int S, int M, int D, int L, int Lq, int P, T *out)
+{
+    if (int rc = check_common(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, sizeof(T))) return rc;
+    SEMIDETR_REQUIRE(out, SEMIDETR_E_BADARG, "msda_forward: null output");
+    const int64_t rows = (int64_t)N * Lq * M;
+    const int blocks = (int)((rows + 3) / 4);
+    hipLaunchKernelGGL(msda_fwd_generic<T>, dim3(blocks), dim3(256), 0, semidetr::as_stream(stream), value,
+                       shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out);
+    return semidetr::launch_status("msda_fwd_generic");
+}
+
+template <typename T>
+int backward_impl(void *stream, const T *gout, const T *value, const int64_t *shapes, const int64_t *starts,
+                  const T *loc, const T *attn, int N, int S, int M, int D, int L, int Lq, int P, T *gvalue,
+                  T *gloc, T *gattn)
+{
+    if (int rc = check_common(value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, sizeof(T))) return rc;
+    SEMIDETR_REQUIRE(gout && gvalue && gloc && gattn, SEMIDETR_E_BADARG, "msda_backward: null pointer argument");
+    hipError_t e = hipMemsetAsync(gvalue, 0, sizeof(T) * (size_t)N * S * M * D, semidetr::as_stream(stream));
+    if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+    const int64_t rows = (int64_t)N * Lq * M;
+    const int blocks = (int)((rows + 3) / 4);
+    hipLaunchKernelGGL(msda_bwd_generic<T>, dim3(blocks), dim3(256), 0, semidetr::as_stream(stream), gout,
+                       value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, gvalue, gloc, gattn);
+    return semidetr::launch_status("msda_bwd_generic");
+}
+
+// fast-path applicability: channels == 32, 16-byte aligned pointers, LDS budget
+bool fast_ok(const void *a, const void *b, const void *c, int D, int L, int P)
+{
+    const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
+    return D == kD && L <= kMaxLevels && (al & 15) == 0 && (int64_t)L * P <= 256;
+}
+
+int pick_split(int forced, int N, int Lq, int M)
+{
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    // enough 32-row workgroups to fill 256 CUs several times over -> no split; otherwise spread the
+    // samples of a row over more lanes so small problems (decoder, 300-900 queries) still fill the chip.
+    const int64_t wg32 = (int64_t)N * M * ((Lq + 31) / 32);
+    if (wg32 >= 2048) return 1;
+    if (wg32 >= 1024) return 2;
+    return 4;
+}
+
+}  // namespace
+
+extern "C" void semidetr_msda_set_variant(int fwd_variant, int bwd_variant)
+{
+    g_fwd_variant = fwd_variant;
+    g_bwd_variant = bwd_variant;
+}
+
+extern "C" int semidetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                         const int64_t *level_start, const float *sampling_loc,
+                                         const float *attn_weight, int batch, int spatial_size,
+                                         int num_heads, int channels, int num_levels, int num_query,
+                                         int num_point, float *out)
+{
+    const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query,
+              P = num_point;
+    if (g_fwd_variant == 99 || !fast_ok(value, sampling_loc, out, D, L, P))
+        return forward_impl<float>(stream, value, spatial_shapes, level_start, sampling_loc, attn_weight, N,
+                                   S, M, D, L, Lq, P, out);
+    if (int rc = check_common(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L,
+                              Lq, P, 4))
+        return rc;
+    SEMIDETR_REQUIRE(out, SEMIDETR_E_BADARG, "msda_forward: null output");
+    const int split = pick_split(g_fwd_variant, N, Lq, M);
+    const int rpb = 32 / split;
+    const int tiles = (Lq + rpb - 1) / rpb;
+    const int64_t grid = (int64_t)N * tiles * M;
+    SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
+    const size_t lds = (size_t)rpb * (L * P + 1) * 32;
+    hipStream_t st = semidetr::as_stream(stream);
+#define LAUNCH_FWD(SP)                                                                                      \
+    hipLaunchKernelGGL(msda_fwd_d32<SP>, dim3((unsigned)grid), dim3(256), lds, st, value, spatial_shapes,   \
+                       level_start, sampling_loc, attn_weight, S, M, L, Lq, P, tiles, out)
+    if (split == 1) LAUNCH_FWD(1);
+    else if (split == 2) LAUNCH_FWD(2);
+    else LAUNCH_FWD(4);
+#undef LAUNCH_FWD
+    return semidetr::launch_status("msda_fwd_d32");
+}
+
+extern "C" int semidetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,
+                                         const int64_t *level_start, const double *sampling_loc,
+                                         const double *attn_weight, int batch, int spatial_size,
+                                         int num_heads, int channels, int num_levels, int num_query,
+                                         int num_point, double *out)
+{
+    return forward_impl<double>(stream, value, spatial_shapes, level_start, sampling_loc, attn_weight, batch,
+                                spatial_size, num_heads, channels, num_levels, num_query, num_point, out);
+}
+
+extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, const float *value,
+                                          const int64_t *spatial_shapes, const int64_t *level_start,
+                                          const float *sampling_loc, const float *attn_weight, int batch,
+                                          int spatial_size, int num_heads, int channels, int num_levels,
+                                          int num_query, int num_point, float *grad_value,
+                                          float *grad_sampling_loc, float *grad_attn_weight)
+{
+    const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query,
+              P = num_point;
+    if (g_bwd_variant == 99 || !fast_ok(value, sampling_loc, grad_out, D, L, P) ||
+        !fast_ok(grad_value, grad_sampling_loc, grad_attn_weight, D, L, P))
+        return backward_impl<float>(stream, grad_out, value, spatial_shapes, level_start, sampling_loc,
+                                    attn_weight, N, S, M, D, L, Lq, P, grad_value, grad_sampling_loc,
+                                    grad_attn_weight);
+    if (int rc = check_common(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L,
+                              Lq, P, 4))
+        return rc;
+    SEMIDETR_REQUIRE(grad_out && grad_value && grad_sampling_loc && grad_attn_weight, SEMIDETR_E_BADARG,
+                     "msda_backward: null pointer argument");
+    hipStream_t st = semidetr::as_stream(stream);
+    hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * D, st);
+    if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+    const int split = pick_split(g_bwd_variant, N, Lq, M);
+    const int rpb = 32 / split;
+    const int tiles = (Lq + rpb - 1) / rpb;
+    const int64_t grid = (int64_t)N * tiles * M;
+    SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+    const size_t lds = (size_t)rpb * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
+#define LAUNCH_BWD(SP)                                                                                      \
+    hipLaunchKernelGGL(msda_bwd_d32<SP>, dim3((unsigned)grid), dim3(256), lds, st, grad_out, value,         \
+                       spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq, P, tiles,       \
+                       grad_value, grad_sampling_loc, grad_attn_weight)
+    if (split == 1) LAUNCH_BWD(1);
+    else if (split == 2) LAUNCH_BWD(2);
+    else LAUNCH_BWD(4);
+#undef LAUNCH_BWD
+    return semidetr::launch_status("msda_bwd_d32");
+}
+
+extern "C" int semidetr_msda_backward_f64(void *stream, const double *grad_out, const double *value,
+                                          const int64_t *spatial_shapes, const int64_t *level_start,
+                                          const double *sampling_loc, const double *attn_weight, int batch,
+                                          int spatial_size, int num_heads, int channels, int num_levels,
+                                          int num_query, int num_point, double *grad_value,
+                                          double *grad_sampling_loc, double *grad_attn_weight)
+{
+    return backward_impl<double>(stream, grad_out, value, spatial_shapes, level_start, sampling_loc,
+                                 attn_weight, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                                 num_point, grad_value, grad_sampling_loc, grad_attn_weight);
+}

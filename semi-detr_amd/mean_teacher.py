@@ -1,0 +1,147 @@
+"""Mean-teacher EMA hook on the MI355X: one fused launch per step instead of ~1000 tiny ones.
+
+Drop-in for ``MeanTeacher`` (detr_ssod/utils/hooks/mean_teacher.py:7-64): same constructor kwargs, same
+hook methods (``before_run`` / ``before_train_iter`` / ``after_train_iter`` / ``momentum_update``), same
+momentum schedule (:46-48), same decay schedule (:52-58), same pairing rule (parameters zipped
+positionally in ``named_parameters()`` order, frozen ones included, buffers untouched, :60-64).
+The arithmetic runs in ``csrc/ema.hip`` through ``semidetr_ema_multi_f32``; the device-side pointer table
+is built once and reused while the parameter storages stay where they are.
+"""
+import ctypes
+from bisect import bisect_right
+
+import torch
+
+from . import _lib
+
+try:  # registered under the reference's name when mmcv is present (see registry.py)
+    from mmcv.parallel import is_module_wrapper
+    from mmcv.runner.hooks import Hook as _HookBase
+except ImportError:  # mmcv is not installed in the build image
+    _HookBase = object
+
+    def is_module_wrapper(module):
+        return isinstance(module, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel))
+
+EMA_CHUNK = 8192   # == SEMIDETR_EMA_CHUNK in include/semidetr_hip.h
+
+
+def ema_momentum(momentum, warm_up, step):
+    """mean_teacher.py:46-48."""
+    return min(momentum, 1 - (1 + warm_up) / (step + 1 + warm_up))
+
+
+class _EmaTable:
+    """Device table {teacher ptr, student ptr, numel, first workgroup} for a list of parameter pairs."""
+
+    def __init__(self, pairs):
+        dev = pairs[0][1].device
+        tp, sp, ne, bs = [], [], [], [0]
+        for src, tgt in pairs:
+            if not (src.is_cuda and tgt.is_cuda and src.device == dev and tgt.device == dev):
+                raise RuntimeError("MeanTeacher: student and teacher parameters must be on one GPU")
+            if src.dtype != torch.float32 or tgt.dtype != torch.float32:
+                raise TypeError("MeanTeacher: only fp32 parameters are supported (the reference trains fp32)")
+            if src.numel() != tgt.numel():
+                raise RuntimeError("MeanTeacher: student/teacher parameter size mismatch")
+            if not (src.is_contiguous() and tgt.is_contiguous()):
+                raise RuntimeError("MeanTeacher: parameters must be contiguous")
+            tp.append(tgt.data_ptr())
+            sp.append(src.data_ptr())
+            ne.append(src.numel())
+            bs.append(bs[-1] + (src.numel() + EMA_CHUNK - 1) // EMA_CHUNK)
+        self.key = (tuple(tp), tuple(sp), tuple(ne))
+        self.device = dev
+        self.num_tensors, self.total_blocks = len(tp), bs[-1]
+        self.total_elems = sum(ne)
+        self.tptr = torch.tensor(tp, dtype=torch.int64, device=dev)
+        self.sptr = torch.tensor(sp, dtype=torch.int64, device=dev)
+        self.numel = torch.tensor(ne, dtype=torch.int64, device=dev)
+        self.starts = torch.tensor(bs, dtype=torch.int32, device=dev)
+
+    @staticmethod
+    def key_of(pairs):
+        return (tuple(t.data_ptr() for _, t in pairs), tuple(s.data_ptr() for s, _ in pairs),
+                tuple(s.numel() for s, _ in pairs))
+
+    def launch(self, momentum):
+        with torch.cuda.device(self.device):
+            rc = _lib.lib().semidetr_ema_multi_f32(
+                _lib.current_stream_ptr(), ctypes.c_void_p(self.tptr.data_ptr()),
+                ctypes.c_void_p(self.sptr.data_ptr()), ctypes.c_void_p(self.numel.data_ptr()),
+                ctypes.c_void_p(self.starts.data_ptr()), self.num_tensors, self.total_blocks, float(momentum))
+        _lib.check(rc, "semidetr_ema_multi_f32")
+
+
+_table_cache = {}
+
+
+def ema_update_(teacher_params, student_params, momentum):
+    """In place: teacher <- momentum * teacher + (1 - momentum) * student for two parameter lists."""
+    pairs = [(s.data, t.data) for s, t in zip(student_params, teacher_params)]
+    pairs = [(s, t) for s, t in pairs if s.numel() > 0]
+    if not pairs:
+        return
+    key = _EmaTable.key_of(pairs)
+    table = _table_cache.get(key)
+    if table is None:
+        if len(_table_cache) > 8:
+            _table_cache.clear()
+        table = _table_cache[key] = _EmaTable(pairs)
+    table.launch(momentum)
+
+
+def ema_update_flat_(teacher_flat, student_flat, momentum):
+    """Same arithmetic on two flat fp32 arenas (parameters laid out contiguously in HBM)."""
+    if not (teacher_flat.is_cuda and student_flat.is_cuda and teacher_flat.dtype == torch.float32
+            and student_flat.dtype == torch.float32 and teacher_flat.is_contiguous()
+            and student_flat.is_contiguous() and teacher_flat.numel() == student_flat.numel()):
+        raise RuntimeError("ema_update_flat_: need two contiguous fp32 GPU tensors of equal size")
+    with torch.cuda.device(teacher_flat.device):
+        rc = _lib.lib().semidetr_ema_flat_f32(
+            _lib.current_stream_ptr(), ctypes.c_void_p(teacher_flat.data_ptr()),
+            ctypes.c_void_p(student_flat.data_ptr()), ctypes.c_int64(teacher_flat.numel()), float(momentum))
+    _lib.check(rc, "semidetr_ema_flat_f32")
+
+
+class MeanTeacher(_HookBase):
+    def __init__(self, momentum=0.999, interval=1, warm_up=100, decay_intervals=None, decay_factor=0.1):
+        assert momentum >= 0 and momentum <= 1
+        self.momentum = momentum
+        assert isinstance(interval, int) and interval > 0
+        self.warm_up = warm_up
+        self.interval = interval
+        assert isinstance(decay_intervals, list) or decay_intervals is None
+        self.decay_intervals = decay_intervals
+        self.decay_factor = decay_factor
+
+    @staticmethod
+    def _unwrap(model):
+        return model.module if is_module_wrapper(model) else model
+
+    def before_run(self, runner):
+        model = self._unwrap(runner.model)
+        assert hasattr(model, "teacher")
+        assert hasattr(model, "student")
+        if runner.iter == 0:       # clone student -> teacher (momentum 0), mean_teacher.py:32-35
+            self.momentum_update(model, 0)
+
+    def before_train_iter(self, runner):
+        curr_step = runner.iter
+        if curr_step % self.interval != 0:
+            return
+        model = self._unwrap(runner.model)
+        momentum = ema_momentum(self.momentum, self.warm_up, curr_step)
+        runner.log_buffer.output["ema_momentum"] = momentum
+        self.momentum_update(model, momentum)
+
+    def after_train_iter(self, runner):
+        curr_step = runner.iter
+        if self.decay_intervals is None:
+            return
+        self.momentum = 1 - (1 - self.momentum) / self.decay_factor ** bisect_right(self.decay_intervals, curr_step)
+
+    def momentum_update(self, model, momentum):
+        students = [p for _, p in model.student.named_parameters()]
+        teachers = [p for _, p in model.teacher.named_parameters()]
+        ema_update_(teachers, students, momentum)

@@ -1,0 +1,93 @@
+"""``MSDeformAttn`` -- the nn.Module around the operator.
+
+Drop-in for detr_od/models/utils/ops/modules/ms_deform_attn.py:30-126: same constructor signature,
+same sub-module names (``sampling_offsets``, ``attention_weights``, ``value_proj``, ``output_proj`` ->
+identical ``state_dict`` keys, so published DINO / Semi-DETR checkpoints load unchanged), same
+initialisation (:62-76), same ``forward`` arguments, errors and arithmetic (:78-126).  The four Linear
+layers are dense GEMMs and stay on hipBLASLt/MFMA through torch; the sampling + aggregation and its
+gradient go through ``MSDeformAttnFunction`` to the hand-written gfx950 kernels.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..functions import MSDeformAttnFunction
+
+
+def _is_power_of_2(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return n != 0 and (n & (n - 1)) == 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a per-head dimension that is not a power of 2 (here {}) takes the "
+                          "generic kernel; 32 channels per head is the tuned gfx950 path."
+                          .format(d_model // n_heads))
+        self.im2col_step = 64        # kept for config/state compatibility; one launch covers the batch
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # ms_deform_attn.py:62-76 -- head m looks along direction 2*pi*m/M, point i at distance i+1
+        nn.init.constant_(self.sampling_offsets.weight.data, 0.0)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = grid / grid.abs().max(-1, keepdim=True)[0]
+        grid = grid.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        grid = grid * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, -1, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.reshape(-1))
+        nn.init.constant_(self.attention_weights.weight.data, 0.0)
+        nn.init.constant_(self.attention_weights.bias.data, 0.0)
+        nn.init.xavier_uniform_(self.value_proj.weight.data)
+        nn.init.constant_(self.value_proj.bias.data, 0.0)
+        nn.init.xavier_uniform_(self.output_proj.weight.data)
+        nn.init.constant_(self.output_proj.bias.data, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """query (N, Lq, C); reference_points (N, Lq, L, 2|4) in [0,1]; input_flatten (N, sum HW, C);
+        input_spatial_shapes (L, 2) [(H, W)]; input_level_start_index (L,); input_padding_mask (N, sum HW)
+        True = padding.  Returns (N, Lq, C)."""
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, M, self.d_model // M)
+        offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
+        weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P), -1).view(N, Len_q, M, L, P)
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            locations = reference_points[:, :, None, :, None, :2] \
+                + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead."
+                             .format(reference_points.shape[-1]))
+
+        if value.dtype == torch.float16:      # amp: the op itself runs in fp32 (ms_deform_attn.py:114-120)
+            output = MSDeformAttnFunction.apply(value.float(), input_spatial_shapes, input_level_start_index,
+                                                locations.float(), weights.float(), self.im2col_step)
+            return self.output_proj(output.to(torch.float16))
+        output = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                            locations.contiguous(), weights.contiguous(), self.im2col_step)
+        return self.output_proj(output)

@@ -1,0 +1,147 @@
+"""GPU parity of the fused mean-teacher EMA and the pseudo-label filter."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp(a, b):
+    return int(np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64)).max())
+
+
+def test_ema_matches_torch_fixture_and_oracle(golden_ema):
+    from semi_detr_amd import ema_update_
+    z = golden_ema.z
+    for mi in range(4):
+        mom = float(z[f"m{mi}.momentum"])
+        teachers = [torch.from_numpy(z[f"m{mi}.t{si}.teacher"].copy()).cuda() for si in range(6)]
+        students = [torch.from_numpy(z[f"m{mi}.t{si}.student"].copy()).cuda() for si in range(6)]
+        ema_update_(teachers, students, mom)
+        for si in range(6):
+            got = teachers[si].cpu().numpy()
+            o = z[f"m{mi}.t{si}.teacher"].copy()
+            oracle.ema_update(o, z[f"m{mi}.t{si}.student"], mom)
+            assert np.array_equal(got, o), "HIP EMA must be bit-identical to the oracle"
+            assert _ulp(got, z[f"m{mi}.t{si}.out"]) <= 1      # torch CPU: mul_ then add_(alpha)
+
+
+def test_ema_large_unaligned_and_flat():
+    from semi_detr_amd import ema_update_, ema_update_flat_
+    torch.manual_seed(1)
+    sizes = [1, 3, 8191, 8192, 8193, 100003, 1 << 20]
+    big_t = torch.randn(sum(sizes) + 16).cuda()
+    big_s = torch.randn(sum(sizes) + 16).cuda()
+    ts, ss, off = [], [], 1                       # offset 1 float -> 4-byte aligned only (scalar path)
+    for n in sizes:
+        ts.append(big_t[off:off + n])
+        ss.append(big_s[off:off + n])
+        off += n
+    want = [t.cpu().numpy().copy() for t in ts]
+    for w, s in zip(want, ss):
+        oracle.ema_update(w, s.cpu().numpy(), 0.999)
+    ema_update_(ts, ss, 0.999)
+    for t, w in zip(ts, want):
+        assert np.array_equal(t.cpu().numpy(), w)
+    a, b = torch.randn(3_000_001).cuda(), torch.randn(3_000_001).cuda()
+    w = a.cpu().numpy().copy()
+    oracle.ema_update(w, b.cpu().numpy(), 0.9996)
+    ema_update_flat_(a, b, 0.9996)
+    assert np.array_equal(a.cpu().numpy(), w)
+
+
+def test_mean_teacher_hook_semantics(golden_ema):
+    """Schedule (mean_teacher.py:46-48), clone at iter 0 (:32-35), interval, frozen params included, buffers
+    untouched, decay schedule (:52-58)."""
+    from semi_detr_amd import MeanTeacher, ema_momentum
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(3, 8, 3)
+            self.bn = torch.nn.BatchNorm2d(8)
+            self.fc = torch.nn.Linear(8, 4)
+            self.conv.weight.requires_grad_(False)       # frozen stem: still averaged
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.teacher, self.student = Net(), Net()
+
+    class Runner:
+        def __init__(self, model):
+            self.model, self.iter = model, 0
+            self.log_buffer = type("LB", (), {"output": {}})()
+
+    z = golden_ema.z
+    for wu in (0, 100):
+        got = [ema_momentum(0.999, wu, int(s)) for s in z["sched_steps"]]
+        assert np.array_equal(np.asarray(got), z[f"sched_wu{wu}"])
+
+    torch.manual_seed(0)
+    model = Model().cuda()
+    model.student.bn.running_mean.fill_(3.0)
+    runner = Runner(model)
+    hook = MeanTeacher(momentum=0.999, interval=2, warm_up=0)
+    hook.before_run(runner)
+    for (_, ps), (_, pt) in zip(model.student.named_parameters(), model.teacher.named_parameters()):
+        assert torch.equal(ps, pt)
+    assert not torch.equal(model.student.bn.running_mean, model.teacher.bn.running_mean)   # buffers untouched
+    ref_t = [p.detach().cpu().numpy().copy() for p in model.teacher.parameters()]
+    for it in range(1, 6):
+        runner.iter = it
+        with torch.no_grad():
+            for p in model.student.parameters():
+                p.add_(torch.randn_like(p) * 0.1)
+        hook.before_train_iter(runner)
+        if it % 2 == 0:
+            m = ema_momentum(0.999, 0, it)
+            assert runner.log_buffer.output["ema_momentum"] == m
+            for r, ps in zip(ref_t, model.student.parameters()):
+                oracle.ema_update(r, ps.detach().cpu().numpy(), m)
+        for r, pt in zip(ref_t, model.teacher.parameters()):
+            assert np.array_equal(pt.detach().cpu().numpy(), r)
+    hook2 = MeanTeacher(momentum=0.999, decay_intervals=[10, 20], decay_factor=0.1)
+    runner.iter = 15
+    hook2.after_train_iter(runner)
+    assert abs(hook2.momentum - (1 - (1 - 0.999) / 0.1)) < 1e-12
+
+
+def test_pseudo_label_filter(golden_pseudo):
+    from semi_detr_amd import filter_pseudo_labels
+    names = golden_pseudo.names()
+    props = [torch.from_numpy(golden_pseudo[n]["proposal"]).cuda() for n in names]
+    labs = [torch.from_numpy(golden_pseudo[n]["labels"]).cuda() for n in names]
+    boxes, labels, scores, thr = filter_pseudo_labels(props, labs, return_threshold=True)
+    for i, n in enumerate(names):
+        g = golden_pseudo[n]
+        keep = g["keep"]
+        assert np.array_equal(boxes[i].cpu().numpy(), g["proposal"][keep, :4]), n
+        assert np.array_equal(scores[i].cpu().numpy(), g["proposal"][keep, 4]), n
+        assert np.array_equal(labels[i].cpu().numpy(), g["labels"][keep]), n
+        ok, othr = oracle.pseudo_label_filter(g["proposal"])
+        assert np.array_equal(ok, keep)
+        if g["proposal"].shape[0] > 1:
+            np.testing.assert_allclose(thr[i].item(), g["thr"], rtol=2e-7)
+        else:
+            assert np.isnan(thr[i].item())
+
+
+def test_pseudo_label_filter_large_ragged():
+    from semi_detr_amd import filter_pseudo_labels
+    rng = np.random.default_rng(4)
+    props, labs = [], []
+    for K in (1000, 0, 257, 256, 255, 3):
+        xy = rng.random((K, 2)) * 800
+        wh = rng.random((K, 2)) * 300 - 30
+        props.append(np.concatenate([xy, xy + wh, rng.random((K, 1)) ** 2], -1).astype(np.float32))
+        labs.append(rng.integers(0, 80, K).astype(np.int64))
+    boxes, labels, scores = filter_pseudo_labels([torch.from_numpy(p).cuda() for p in props],
+                                                 [torch.from_numpy(l).cuda() for l in labs])
+    for p, l, b, la, s in zip(props, labs, boxes, labels, scores):
+        keep, _ = oracle.pseudo_label_filter(p)
+        assert np.array_equal(b.cpu().numpy(), p[keep, :4])
+        assert np.array_equal(la.cpu().numpy(), l[keep])
+        assert np.array_equal(s.cpu().numpy(), p[keep, 4])

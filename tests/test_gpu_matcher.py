@@ -1,0 +1,164 @@
+"""GPU parity of the matcher: cost matrix vs the reference-generated fixtures (<= 1e-5) and the oracle,
+the on-device LSAP bit-exact vs scipy on the same matrix, and HungarianAssigner end to end."""
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import linear_sum_assignment as scipy_lsa
+
+import oracle
+from conftest import Golden
+
+pytestmark = pytest.mark.gpu
+COST_CASES = Golden("cost.npz").names()
+LSAP_CASES = Golden("lsap.npz").names()
+
+DINO_ASSIGNER = dict(cls_cost=dict(type="FocalLossCost", weight=2.0),
+                     reg_cost=dict(type="BBoxL1Cost", weight=5.0, box_format="xywh"),
+                     iou_cost=dict(type="IoUCost", iou_mode="giou", weight=2.0))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _meta(wh):
+    return dict(img_shape=(int(wh[1]), int(wh[0]), 3))
+
+
+@pytest.mark.parametrize("case", COST_CASES)
+def test_cost_and_assignment_match_reference(case, golden_cost):
+    from semi_detr_amd import HungarianAssigner
+    g = golden_cost[case]
+    asg = HungarianAssigner(**DINO_ASSIGNER)
+    res, costs, raw = asg.assign_batch(_t(g["bbox_pred"])[None], _t(g["cls_pred"])[None], [_t(g["gt_bboxes"])],
+                                       [_t(g["gt_labels"])], [_meta(g["img_wh"])], return_cost=True)
+    G = g["gt_bboxes"].shape[0]
+    if G:
+        cost = costs[0].cpu().numpy()
+        np.testing.assert_allclose(cost, g["cost"], rtol=1e-5, atol=1e-5)      # SURVEY B.3 bar
+        w, h = g["img_wh"]
+        o = oracle.match_cost(g["bbox_pred"], g["cls_pred"], g["gt_bboxes"], g["gt_labels"], w, h)
+        np.testing.assert_allclose(cost, o, rtol=2e-6, atol=2e-6)
+        # solver given OUR matrix: bit-exact with scipy
+        r, c = scipy_lsa(cost)
+        assert np.array_equal(raw["rows"].cpu().numpy(), r) and np.array_equal(raw["cols"].cpu().numpy(), c)
+    # end to end vs the reference pipeline (indices bit-exact, BASELINE.json north_star)
+    assert res[0].num_gts == G
+    assert np.array_equal(res[0].gt_inds.cpu().numpy(), g["assigned_gt_inds"])
+    assert np.array_equal(res[0].labels.cpu().numpy(), g["assigned_labels"])
+    one = asg.assign(_t(g["bbox_pred"]), _t(g["cls_pred"]), _t(g["gt_bboxes"]), _t(g["gt_labels"]),
+                     _meta(g["img_wh"]))
+    assert np.array_equal(one.gt_inds.cpu().numpy(), g["assigned_gt_inds"])
+
+
+def test_individual_costs_callable_like_reference(golden_cost):
+    """dino_detr_ssod.py:265-271 calls assigner.cls_cost / reg_cost / iou_cost one by one."""
+    from semi_detr_amd import HungarianAssigner
+    g = golden_cost[[c for c in COST_CASES if "Q300_G7" in c][0]]
+    asg = HungarianAssigner(**DINO_ASSIGNER)
+    w, h = g["img_wh"]
+    factor = torch.tensor([w, h, w, h]).cuda()
+    bp, cp, gb, gl = _t(g["bbox_pred"]), _t(g["cls_pred"]), _t(g["gt_bboxes"]), _t(g["gt_labels"])
+    c1 = asg.cls_cost(cp, gl)
+    c2 = asg.reg_cost(bp, gb / factor)
+    xyxy = torch.cat([bp[:, :2] - 0.5 * bp[:, 2:], bp[:, :2] + 0.5 * bp[:, 2:]], -1) * factor
+    c3 = asg.iou_cost(xyxy, gb)
+    np.testing.assert_allclose(c1.cpu().numpy(), g["cost_cls"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c2.cpu().numpy(), g["cost_reg"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c3.cpu().numpy(), g["cost_iou"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose((c1 + c2 + c3).cpu().numpy(), g["cost"], rtol=1e-5, atol=1e-5)
+
+
+def test_ioucost_docstring_known_answer():
+    from semi_detr_amd import IoUCost
+    got = IoUCost()(torch.FloatTensor([[1, 1, 2, 2], [2, 2, 3, 4]]).cuda(),
+                    torch.FloatTensor([[0, 0, 2, 4], [1, 2, 3, 4]]).cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), [[-0.1250, 0.1667], [0.1667, -0.5000]], atol=1e-4)
+
+
+@pytest.mark.parametrize("case", LSAP_CASES)
+def test_lsap_golden(case, golden_lsap):
+    from semi_detr_amd import linear_sum_assignment
+    g = golden_lsap[case]
+    c32 = g["cost"].astype(np.float32)
+    if not np.array_equal(c32.astype(np.float64), g["cost"]):
+        pytest.skip("fixture not exactly representable in fp32")
+    r, c = linear_sum_assignment(_t(c32))
+    assert r.dtype == torch.int64 and c.dtype == torch.int64
+    assert np.array_equal(r.cpu().numpy(), g["rows"]) and np.array_equal(c.cpu().numpy(), g["cols"])
+
+
+def test_lsap_random_bit_exact_vs_scipy():
+    """Heavy ties, +inf entries, both orientations, sizes up to the DINO problem (900 x 100)."""
+    from semi_detr_amd import linear_sum_assignment
+    rng = np.random.default_rng(2024)
+    shapes = [(int(rng.integers(1, 70)), int(rng.integers(1, 70))) for _ in range(160)]
+    shapes += [(900, 1), (900, 7), (900, 30), (900, 100), (300, 300), (5, 900), (1100, 40), (64, 64), (65, 63)]
+    for t, (nr, nc) in enumerate(shapes):
+        kind = t % 4
+        if kind == 0:
+            c = rng.random((nr, nc))
+        elif kind == 1:
+            c = rng.integers(0, 3, (nr, nc)).astype(float)
+        elif kind == 2:
+            c = np.round(rng.random((nr, nc)) * 4) / 4
+            c[rng.random((nr, nc)) < 0.1] = np.inf
+        else:
+            c = rng.standard_normal((nr, nc))
+        c = c.astype(np.float32)
+        try:
+            want = scipy_lsa(c)
+        except ValueError as e:
+            with pytest.raises(ValueError, match=str(e)[:20]):
+                linear_sum_assignment(_t(c))
+            continue
+        r, cc = linear_sum_assignment(_t(c))
+        assert np.array_equal(r.cpu().numpy(), want[0]) and np.array_equal(cc.cpu().numpy(), want[1]), (t, nr, nc)
+
+
+def test_lsap_errors_and_empty():
+    from semi_detr_amd import linear_sum_assignment
+    with pytest.raises(ValueError, match="invalid numeric"):
+        linear_sum_assignment(torch.tensor([[float("nan"), 1.0]]).cuda())
+    with pytest.raises(ValueError, match="invalid numeric"):
+        linear_sum_assignment(torch.tensor([[float("-inf"), 1.0]]).cuda())
+    with pytest.raises(ValueError, match="infeasible"):
+        linear_sum_assignment(torch.full((2, 2), float("inf")).cuda())
+    r, c = linear_sum_assignment(torch.zeros(0, 3).cuda())
+    assert r.numel() == 0 and c.numel() == 0
+
+
+def test_large_workspace_path_vs_scipy():
+    """Q large enough that the solver state leaves LDS (global workspace variant)."""
+    from semi_detr_amd import linear_sum_assignment
+    rng = np.random.default_rng(9)
+    c = rng.standard_normal((5000, 12)).astype(np.float32)
+    r, cc = linear_sum_assignment(_t(c))
+    want = scipy_lsa(c)
+    assert np.array_equal(r.cpu().numpy(), want[0]) and np.array_equal(cc.cpu().numpy(), want[1])
+
+
+def test_assign_batch_ragged_like_a_loss_call():
+    """7 decoder layers x 5 images, ragged gt counts including 0 -- one launch each; every problem must equal
+    the oracle pipeline (cost -> scipy-exact LSAP -> scatter) on OUR cost matrix and the oracle's."""
+    from semi_detr_amd import HungarianAssigner
+    rng = np.random.default_rng(77)
+    B, Q, C = 35, 900, 80
+    counts = [int(x) for x in rng.integers(0, 16, B)]
+    counts[3] = 0
+    counts[7] = 100
+    bp = np.concatenate([rng.random((B, Q, 2)), rng.random((B, Q, 2)) * 0.5 + 0.01], -1).astype(np.float32)
+    cp = (rng.standard_normal((B, Q, C)) * 3).astype(np.float32)
+    gts, labs, metas = [], [], []
+    for b in range(B):
+        xy = rng.random((counts[b], 2)) * [1000, 600]
+        wh = rng.random((counts[b], 2)) * [300, 200] + 16
+        gts.append(np.concatenate([xy, xy + wh], -1).astype(np.float32))
+        labs.append(rng.integers(0, C, counts[b]).astype(np.int64))
+        metas.append(dict(img_shape=(800, 1333 - 7 * (b % 3), 3)))
+    asg = HungarianAssigner(**DINO_ASSIGNER)
+    res = asg.assign_batch(_t(bp), _t(cp), [_t(g) for g in gts], [_t(l) for l in labs], metas)
+    for b in range(B):
+        gi, lab, _, _ = oracle.hungarian_assign(bp[b], cp[b], gts[b], labs[b], metas[b]["img_shape"][1], 800)
+        assert np.array_equal(res[b].gt_inds.cpu().numpy(), gi), b
+        assert np.array_equal(res[b].labels.cpu().numpy(), lab), b

@@ -1,0 +1,62 @@
+"""GPU: MSDeformAttn (nn.Module boundary) against the fixture produced by the reference's own module
+(detr_od/models/utils/ops/modules/ms_deform_attn.py:30-126) -- state_dict compatibility + arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["ref2", "ref4"])
+def test_module_matches_reference(name, golden_module):
+    from semi_detr_amd import MSDeformAttn
+    g = golden_module[name]
+    m = MSDeformAttn(d_model=32, n_levels=3, n_heads=4, n_points=2).double()
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    m.load_state_dict(sd, strict=True)          # identical key set is part of the drop-in contract
+    m = m.cuda()
+    shapes = torch.from_numpy(g["shapes"]).cuda()
+    ls = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    mask = torch.from_numpy(g["mask"]).cuda() if "mask" in g else None
+    out = m(torch.from_numpy(g["query"]).cuda(), torch.from_numpy(g["ref"]).cuda(),
+            torch.from_numpy(g["src"]).cuda(), shapes, ls, mask)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-10, atol=1e-12)
+
+
+def test_module_fp32_backward_runs_and_matches_fp64():
+    from semi_detr_amd import MSDeformAttn
+    torch.manual_seed(0)
+    m32 = MSDeformAttn(256, 4, 8, 4).cuda()
+    with torch.no_grad():
+        m32.sampling_offsets.weight.normal_(0, 0.02)
+        m32.attention_weights.weight.normal_(0, 0.1)
+    m64 = MSDeformAttn(256, 4, 8, 4).cuda().double()
+    m64.load_state_dict({k: v.double() for k, v in m32.state_dict().items()})
+    levels = [(20, 27), (10, 14), (5, 7), (3, 4)]
+    shapes = torch.as_tensor(levels, dtype=torch.long).cuda()
+    ls = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    S = sum(h * w for h, w in levels)
+    q = torch.randn(2, 50, 256).cuda().requires_grad_(True)
+    src = torch.randn(2, S, 256).cuda().requires_grad_(True)
+    ref = torch.rand(2, 50, 4, 4).cuda()
+    ref[..., 2:] = ref[..., 2:] * 0.2 + 0.05
+    o32 = m32(q, ref, src, shapes, ls)
+    o32.square().sum().backward()
+    q64, s64 = q.detach().double().requires_grad_(True), src.detach().double().requires_grad_(True)
+    o64 = m64(q64, ref.double(), s64, shapes, ls)
+    o64.square().sum().backward()
+    assert torch.allclose(o32.double(), o64, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(q.grad.double(), q64.grad, rtol=1e-2, atol=1e-3)
+    assert torch.allclose(src.grad.double(), s64.grad, rtol=1e-2, atol=1e-3)
+    assert torch.allclose(m32.value_proj.weight.grad.double(), m64.value_proj.weight.grad, rtol=1e-2, atol=1e-2)
+
+
+def test_module_errors():
+    from semi_detr_amd import MSDeformAttn
+    with pytest.raises(ValueError, match="d_model must be divisible by n_heads"):
+        MSDeformAttn(d_model=30, n_heads=8)
+    m = MSDeformAttn(32, 1, 4, 1).cuda()
+    shapes = torch.as_tensor([(2, 2)], dtype=torch.long).cuda()
+    with pytest.raises(ValueError, match="Last dim of reference_points must be 2 or 4"):
+        m(torch.zeros(1, 1, 32).cuda(), torch.zeros(1, 1, 1, 3).cuda(), torch.zeros(1, 4, 32).cuda(), shapes,
+          shapes.new_zeros(1))

@@ -1,0 +1,46 @@
+"""CPU: the C oracle (oracle/msda_oracle.c) against fixtures generated from the reference's own
+ms_deform_attn_core_pytorch + autograd (oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import Golden, kink_mask, skipped_sample_mask
+
+CASES = Golden("msda.npz").names()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_forward_matches_reference(case, golden_msda):
+    g = golden_msda[case]
+    out = oracle.msda_forward(g["value"], g["shapes"], g["loc"], g["attn"])
+    tol = 1e-15 if g["value"].dtype == np.float64 else 2e-8
+    assert out.dtype == g["out"].dtype and out.shape == g["out"].shape
+    np.testing.assert_allclose(out, g["out"], rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_backward_matches_reference(case, golden_msda):
+    g = golden_msda[case]
+    gv, gl, ga = oracle.msda_backward(g["value"], g["shapes"], g["loc"], g["attn"], g["gout"])
+    f64 = g["value"].dtype == np.float64
+    np.testing.assert_allclose(gv, g["gvalue"], rtol=0, atol=1e-14 if f64 else 5e-7)
+    np.testing.assert_allclose(ga, g["gattn"], rtol=0, atol=1e-14 if f64 else 5e-7)
+    keep = ~kink_mask(g["loc"], g["shapes"])
+    assert keep.mean() > 0.05
+    np.testing.assert_allclose(gl[keep], g["gloc"][keep], rtol=0, atol=1e-13 if f64 else 5e-6)
+    # exactly on the skip boundary the CUDA semantics (strict inequalities) give exactly zero
+    assert np.all(gl[skipped_sample_mask(g["loc"], g["shapes"])] == 0)
+
+
+def test_oracle_zero_outside_and_linearity():
+    rng = np.random.default_rng(0)
+    shapes = np.array([[5, 4], [2, 3]], np.int64)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = rng.random((1, S, 2, 8)).astype(np.float64)
+    loc = rng.random((1, 6, 2, 2, 3, 2)) + 2.0          # everything far outside -> all samples skipped
+    attn = rng.random((1, 6, 2, 2, 3))
+    assert np.all(oracle.msda_forward(value, shapes, loc, attn) == 0)
+    loc = rng.random((1, 6, 2, 2, 3, 2))
+    a = oracle.msda_forward(value, shapes, loc, attn)
+    b = oracle.msda_forward(2 * value, shapes, loc, attn)
+    np.testing.assert_allclose(b, 2 * a, rtol=1e-14)
