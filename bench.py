@@ -338,7 +338,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Semi-DETR COCO-10% teacher-student step, hot path only, per GPU 1 labeled + 4 "
+            "config": {"workload": "Semi-DETR COCO-10%% teacher-student step, hot path only, per GPU 1 labeled + 4 "
                                    "unlabeled 800x1333 images: 60 MSDA fwd + 24 MSDA bwd launches (S=22223, M=8, "
                                    "D=32, L=4, P=4, Lq=22223/900/1100), 39 Hungarian problems (Q=900, G~U[1,15]), "
                                    "EMA over %d params, pseudo-label filter; dense GEMMs/backbone not included"

@@ -13,6 +13,10 @@ import torch
 from . import _lib
 
 
+_SCALAR_NAMES = {torch.float16: "Half", torch.bfloat16: "BFloat16", torch.int32: "Int", torch.int64: "Long",
+                 torch.uint8: "Byte", torch.int8: "Char", torch.int16: "Short", torch.bool: "Bool"}
+
+
 def _assert(cond, msg):
     if not cond:
         raise RuntimeError(msg)   # what AT_ASSERTM raises on the Python side
@@ -42,7 +46,7 @@ def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, i
     _assert(spatial_shapes.dtype == torch.int64, "expected scalar type Long for spatial_shapes")
     _assert(level_start_index.dtype == torch.int64, "expected scalar type Long for level_start_index")
     _assert(value.dtype in (torch.float32, torch.float64),
-            f'"{what}" not implemented for \'{str(value.dtype).replace("torch.", "")}\'')
+            f'"{what}" not implemented for \'{_SCALAR_NAMES.get(value.dtype, str(value.dtype))}\'')
     _assert(sampling_loc.dtype == value.dtype and attn_weight.dtype == value.dtype,
             f"{what}: value, sampling_loc and attn_weight must share one dtype")
     _assert(tuple(sampling_loc.shape) == (batch, num_query, num_heads, num_levels, num_point, 2)

@@ -194,8 +194,8 @@ def test_full_size_properties(Lq):
     shapes = torch.as_tensor(LEVELS, dtype=torch.long).cuda()
     ls = _level_start(shapes)
     S = int((shapes[:, 0] * shapes[:, 1]).sum())
-    # interior samples: keep half a pixel away from the border so all 4 corners are valid
-    lo_xy = torch.tensor([[0.5 / w, 0.5 / h] for h, w in LEVELS]).cuda().view(1, 1, 1, L, 1, 2)
+    # interior samples: keep one pixel away from the border so all 4 corners are valid (robust to rounding)
+    lo_xy = torch.tensor([[1.0 / w, 1.0 / h] for h, w in LEVELS]).cuda().view(1, 1, 1, L, 1, 2)
     loc = lo_xy + torch.rand(N, Lq, M, L, P, 2).cuda() * (1 - 2 * lo_xy) * 0.999
     attn = torch.rand(N, Lq, M, L, P).cuda() + 1e-5
     attn = attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
@@ -218,7 +218,7 @@ def test_full_size_properties(Lq):
     assert abs(lhs - rhs) / abs(rhs) < 1e-5
     # the constant map has zero spatial gradient
     _, gl_c, _ = MSDA.ms_deform_attn_backward(const, shapes, ls, loc, attn, g, 64)
-    assert gl_c.abs().max() < 1e-2 * g.abs().max() * 1e-2
+    assert gl_c.abs().max() < 1e-4
     assert torch.isfinite(gl).all()
 
 
