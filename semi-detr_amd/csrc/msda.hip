@@ -282,14 +282,31 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     }
 }
 
-template <int SPLIT>
+// Sum over the 32 lanes of each wavefront half (lane = channel).  After the five steps lanes 16..31 of
+// each half hold the half's total; the writer is lane 16 / 48.
+__device__ __forceinline__ float half32_sum(float x)
+{
+    x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);   // row_half_mirror
+    x += dpp_mov<0x140>(x);   // row_mirror  -> every lane of a 16-lane row holds the row total
+    // row_bcast:15 into rows 1 and 3 (row_mask 0xA): lane 15 of the previous row is added to every lane
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, true));
+    return x;
+}
+
+// Backward, fp32 / D == 32.  One value row (128 B) per 32 lanes, lane = channel: every global_atomic_add_f32
+// wave-instruction updates two COMPLETE cache lines.  Measured on MI355X (tools/atomic_probe.hip): L2 fp32
+// atomics cost ~one unit per 64-byte half-line touched (~20.8 G units/s chip-wide), so full-row updates move
+// 4x more gradient per unit than the 8-lane x float4 layout the forward uses.
+// RPB = query rows per 256-thread workgroup (8 half-waves, each walks RPB/8 rows).
+template <int RPB>
 __global__ __launch_bounds__(256) void msda_bwd_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn,
     int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ gvalue,
     float *__restrict__ gloc, float *__restrict__ gattn)
 {
-    constexpr int RPB = 32 / SPLIT;
     extern __shared__ float4 smem[];
     const int LP = L * P, LPP = LP + 1;
     int4 *rec_off = reinterpret_cast<int4 *>(smem);
@@ -324,66 +341,42 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
     }
     __syncthreads();
 
-    const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
-    const int r = g / SPLIT, part = g % SPLIT;
-    const int q = t.q0 + r;
-    const int64_t vo = ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
+    const int hw = threadIdx.x >> 5, c = threadIdx.x & 31;      // half-wave index, channel
+    const int64_t vo = ((int64_t)t.n * S * M + t.m) * kD + c;
     const float *vb = value + vo;
     float *gvb = gvalue + vo;
-    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < Lq) {
+    for (int r = hw; r < RPB; r += 8) {
+        const int q = t.q0 + r;
+        if (q >= Lq) break;
         const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
-        go = *reinterpret_cast<const float4 *>(gout + row * kD + 4 * j);
-    }
-    const int4 *ro = rec_off + r * LPP;
-    float4 *rp = rec_p + r * LPP;
-#pragma unroll 2
-    for (int k = part; k < LP; k += SPLIT) {
-        const int4 o = ro[k];
-        const float4 pr = rp[k];
-        const float lw = pr.x, lh = pr.y, a = pr.z;
-        const int l = __float_as_int(pr.w);
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        const float4 v1 = ld4(vb, o.x), v2 = ld4(vb, o.y), v3 = ld4(vb, o.z), v4 = ld4(vb, o.w);
-        const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
-        if (o.x >= 0) {
-            float *p = gvb + o.x;
-            fp_atomic_add(p, w1 * ga.x); fp_atomic_add(p + 1, w1 * ga.y);
-            fp_atomic_add(p + 2, w1 * ga.z); fp_atomic_add(p + 3, w1 * ga.w);
+        const float go = gout[row * kD + c];
+        const int4 *ro = rec_off + r * LPP;
+        float4 *rp = rec_p + r * LPP;
+#pragma unroll 4
+        for (int k = 0; k < LP; ++k) {
+            const int4 o = ro[k];
+            const float4 pr = rp[k];
+            const float lw = pr.x, lh = pr.y, a = pr.z;
+            const int l = __float_as_int(pr.w);
+            const float hh = 1.f - lh, hwt = 1.f - lw;
+            const float ga = go * a;
+            float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+            if (o.x >= 0) v1 = vb[o.x];
+            if (o.y >= 0) v2 = vb[o.y];
+            if (o.z >= 0) v3 = vb[o.z];
+            if (o.w >= 0) v4 = vb[o.w];
+            if (o.x >= 0) fp_atomic_add(gvb + o.x, hh * hwt * ga);
+            if (o.y >= 0) fp_atomic_add(gvb + o.y, hh * lw * ga);
+            if (o.z >= 0) fp_atomic_add(gvb + o.z, lh * hwt * ga);
+            if (o.w >= 0) fp_atomic_add(gvb + o.w, lh * lw * ga);
+            float pa = go * (hh * hwt * v1 + hh * lw * v2 + lh * hwt * v3 + lh * lw * v4);
+            float px = ga * (hh * (v2 - v1) + lh * (v4 - v3));
+            float py = ga * (hwt * (v3 - v1) + lw * (v4 - v2));
+            pa = half32_sum(pa);
+            px = half32_sum(px);
+            py = half32_sum(py);
+            if (c == 16) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, 0.f);
         }
-        if (o.y >= 0) {
-            float *p = gvb + o.y;
-            fp_atomic_add(p, w2 * ga.x); fp_atomic_add(p + 1, w2 * ga.y);
-            fp_atomic_add(p + 2, w2 * ga.z); fp_atomic_add(p + 3, w2 * ga.w);
-        }
-        if (o.z >= 0) {
-            float *p = gvb + o.z;
-            fp_atomic_add(p, w3 * ga.x); fp_atomic_add(p + 1, w3 * ga.y);
-            fp_atomic_add(p + 2, w3 * ga.z); fp_atomic_add(p + 3, w3 * ga.w);
-        }
-        if (o.w >= 0) {
-            float *p = gvb + o.w;
-            fp_atomic_add(p, w4 * ga.x); fp_atomic_add(p + 1, w4 * ga.y);
-            fp_atomic_add(p + 2, w4 * ga.z); fp_atomic_add(p + 3, w4 * ga.w);
-        }
-        // per-lane partials over its 4 channels, then the 8-lane group sum
-        float pa = go.x * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) +
-                   go.y * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) +
-                   go.z * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) +
-                   go.w * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
-        float px = ga.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) +
-                   ga.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
-                   ga.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) +
-                   ga.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
-        float py = ga.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) +
-                   ga.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
-                   ga.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) +
-                   ga.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
-        pa = group8_sum(pa);
-        px = group8_sum(px);
-        py = group8_sum(py);
-        if (j == 0) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, 0.f);
     }
     __syncthreads();
 
@@ -398,6 +391,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
         *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
     }
 }
+
 
 int g_fwd_variant = 0, g_bwd_variant = 0;
 
@@ -534,19 +528,19 @@ extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, c
     hipStream_t st = semidetr::as_stream(stream);
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * D, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    const int split = pick_split(g_bwd_variant, N, Lq, M);
-    const int rpb = 32 / split;
+    // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles
+    int rpb = (int64_t)N * M * ((Lq + 31) / 32) >= 1024 ? 32 : 8;
+    if (g_bwd_variant == 8 || g_bwd_variant == 32) rpb = g_bwd_variant;
     const int tiles = (Lq + rpb - 1) / rpb;
     const int64_t grid = (int64_t)N * tiles * M;
     SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
     const size_t lds = (size_t)rpb * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
-#define LAUNCH_BWD(SP)                                                                                      \
-    hipLaunchKernelGGL(msda_bwd_d32<SP>, dim3((unsigned)grid), dim3(256), lds, st, grad_out, value,         \
+#define LAUNCH_BWD(R)                                                                                       \
+    hipLaunchKernelGGL(msda_bwd_d32<R>, dim3((unsigned)grid), dim3(256), lds, st, grad_out, value,          \
                        spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq, P, tiles,       \
                        grad_value, grad_sampling_loc, grad_attn_weight)
-    if (split == 1) LAUNCH_BWD(1);
-    else if (split == 2) LAUNCH_BWD(2);
-    else LAUNCH_BWD(4);
+    if (rpb == 32) LAUNCH_BWD(32);
+    else LAUNCH_BWD(8);
 #undef LAUNCH_BWD
     return semidetr::launch_status("msda_bwd_d32");
 }

@@ -85,13 +85,13 @@ def _random_case(seed, shapes, N, M, D, Lq, P, dtype, wide=True):
     return value, shapes, loc.astype(dtype), attn.astype(dtype), gout.astype(dtype)
 
 
-@pytest.mark.parametrize("fwd_bwd_variant", [1, 2, 4, 99])
-@pytest.mark.parametrize("Lq", [1, 31, 32, 33, 300])
-def test_fast_path_variants_vs_oracle(fwd_bwd_variant, Lq):
-    """Every forced kernel variant of the fp32 / D=32 path (split 1/2/4 and the generic kernel = 99),
-    ragged query counts around the 32-row tile."""
+@pytest.mark.parametrize("variants", [(1, 8), (2, 32), (4, 8), (99, 99)])
+@pytest.mark.parametrize("Lq", [1, 7, 8, 9, 31, 32, 33, 300])
+def test_fast_path_variants_vs_oracle(variants, Lq):
+    """Every forced kernel variant of the fp32 / D=32 path (forward split 1/2/4, backward 8/32 rows per
+    workgroup, and the generic kernel = 99), ragged query counts around the tile sizes."""
     import semi_detr_amd
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(fwd_bwd_variant, fwd_bwd_variant)
+    semi_detr_amd._lib.lib().semidetr_msda_set_variant(*variants)
     case = _random_case(40 + Lq, [(20, 27), (10, 14), (5, 7), (3, 4)], 2, 8, 32, Lq, 4, np.float32)
     out, gv, gl, ga = _run(*case)
     o_out = oracle.msda_forward(*case[:4])

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Probe for profiling / tuning: run one MSDA shape `iters` times (forward and/or backward) with a forced
+kernel variant and print event-timed microseconds per launch.
+    python tools/msda_probe.py --shape enc --bs 4 --dir fwd --variant 1 --iters 20"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="enc", choices=["enc", "dec", "micro"])
+    ap.add_argument("--bs", type=int, default=4)
+    ap.add_argument("--lq", type=int, default=1100)
+    ap.add_argument("--dir", default="both", choices=["fwd", "bwd", "both"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--sigma", type=float, default=2.0, help="encoder sample spread in pixels")
+    a = ap.parse_args()
+    import semi_detr_amd as sda
+    import MultiScaleDeformableAttention as MSDA
+    sda._lib.lib().semidetr_msda_set_variant(a.variant, a.variant)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    S, M, D, L, P, LEVELS = bench.S, bench.M, bench.D, bench.L, bench.P, bench.LEVELS
+    shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    n = a.bs
+    value = torch.rand(n, S, M, D, device=dev) * 0.01
+    if a.shape == "enc":
+        lq = S
+        ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h,
+                                                    (torch.arange(w, device=dev) + 0.5) / w, indexing="ij"),
+                                     -1).flip(-1).reshape(-1, 2) for h, w in LEVELS])
+        inv = torch.tensor([[a.sigma / w, a.sigma / h] for h, w in LEVELS], device=dev).view(1, 1, 1, L, 1, 2)
+        loc = (ref.view(1, S, 1, 1, 1, 2) + torch.randn(n, S, M, L, P, 2, device=dev) * inv).contiguous()
+    else:
+        lq = 300 if a.shape == "micro" else a.lq
+        loc = torch.rand(n, lq, M, L, P, 2, device=dev)
+    attn = torch.rand(n, lq, M, L, P, device=dev) + 1e-5
+    attn = attn / attn.sum((-1, -2), keepdim=True)
+    gout = torch.rand(n, lq, M * D, device=dev)
+    runs = []
+    if a.dir in ("fwd", "both"):
+        runs.append(("fwd", lambda: MSDA.ms_deform_attn_forward(value, shapes, starts, loc, attn, 64), False))
+    if a.dir in ("bwd", "both"):
+        runs.append(("bwd", lambda: MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn, gout, 64), True))
+    for name, fn, bw in runs:
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.iters
+        b = bench.msda_alg_bytes(n, lq, bw)
+        print(f"{a.shape} bs{n} Lq{lq} {name} variant{a.variant}: {us:9.1f} us  alg {b/1e6:8.1f} MB  "
+              f"{b/us/1e3:8.1f} GB/s  ({b/us/1e3/80:5.1f}% of 8 TB/s)")
+
+
+if __name__ == "__main__":
+    main()
