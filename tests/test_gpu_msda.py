@@ -115,6 +115,43 @@ def test_fast_path_generic_heads_levels_points(M, L, P):
     np.testing.assert_allclose(ga, o_ga, rtol=0, atol=F32_GRAD_ATOL)
 
 
+@pytest.mark.parametrize("shapes,M,P,mode", [
+    ([(20, 27), (10, 14), (5, 7), (3, 4)], 8, 4, "near"),       # DINO-like pyramid, clustered samples
+    ([(20, 27), (10, 14), (5, 7), (3, 4)], 8, 4, "far"),        # same, samples anywhere (window misses)
+    ([(1, 200), (3, 1)], 2, 3, "near"),                         # degenerate levels: many patches per bound
+    ([(17, 9)], 3, 1, "near"),                                  # single level, ragged patches, odd head count
+    ([(9, 33), (5, 17), (3, 9), (2, 5), (1, 3)], 8, 4, "wide"), # five levels, samples partly outside
+])
+@pytest.mark.parametrize("variant", [0, 32])
+def test_encoder_self_attention_backward_vs_oracle(shapes, M, P, mode, variant):
+    """num_query == spatial_size selects the LDS-window backward kernel (variant 0); variant 32 forces the
+    plain kernel on the same inputs.  Both must match the oracle."""
+    import semi_detr_amd
+    semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, variant)
+    rng = np.random.default_rng(len(shapes) * 100 + M + P)
+    shp = np.asarray(shapes, np.int64)
+    L, N, D = len(shapes), 2, 32
+    S = int((shp[:, 0] * shp[:, 1]).sum())
+    ref = np.concatenate([np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1)
+                          .reshape(-1, 2) for h, w in shapes])
+    if mode == "near":
+        loc = ref[None, :, None, None, None, :] + rng.standard_normal((N, S, M, L, P, 2)) * (2.0 / shp[None, None, None, :, None, ::-1])
+    elif mode == "far":
+        loc = rng.random((N, S, M, L, P, 2))
+    else:
+        loc = ref[None, :, None, None, None, :] + rng.standard_normal((N, S, M, L, P, 2)) * 0.3
+    value = (rng.random((N, S, M, D)) * 0.01).astype(np.float32)
+    attn = rng.random((N, S, M, L, P)) + 1e-5
+    attn /= attn.sum((-1, -2), keepdims=True)
+    gout = rng.random((N, S, M * D)).astype(np.float32)
+    case = (value, shp, loc.astype(np.float32), attn.astype(np.float32), gout)
+    out, gv, gl, ga = _run(*case)
+    o_gv, o_gl, o_ga = oracle.msda_backward(*case)
+    np.testing.assert_allclose(gv, o_gv, rtol=1e-5, atol=F32_GRAD_ATOL)
+    np.testing.assert_allclose(gl, o_gl, rtol=1e-5, atol=F32_GRAD_ATOL)
+    np.testing.assert_allclose(ga, o_ga, rtol=1e-5, atol=F32_GRAD_ATOL)
+
+
 @pytest.mark.parametrize("D", [30, 32, 64, 71, 1025, 2048, 3096])
 def test_channel_counts_of_reference_test_py_fp64(D):
     """ops/test.py:85-86 runs gradcheck for exactly these channel counts (one per CUDA dispatch branch)."""

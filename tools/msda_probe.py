@@ -20,11 +20,12 @@ def main():
     ap.add_argument("--dir", default="both", choices=["fwd", "bwd", "both"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--fvariant", type=int, default=None)
     ap.add_argument("--sigma", type=float, default=2.0, help="encoder sample spread in pixels")
     a = ap.parse_args()
     import semi_detr_amd as sda
     import MultiScaleDeformableAttention as MSDA
-    sda._lib.lib().semidetr_msda_set_variant(a.variant, a.variant)
+    sda._lib.lib().semidetr_msda_set_variant(a.variant if a.fvariant is None else a.fvariant, a.variant)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     S, M, D, L, P, LEVELS = bench.S, bench.M, bench.D, bench.L, bench.P, bench.LEVELS
