@@ -333,6 +333,12 @@ def main():
         dom = msda[dom_name]
         dur_s = dom["ms"] * 1e-3 / dom["launches"]
         achieved = dom["bytes"] / dur_s / 1e9
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (bench.py cannot collect counters itself)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc.get(dom_name, {}).get("hbm_bytes_corrected")
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "images/sec/node DINO-R50 SSOD step (hot path: MSDA fwd/bwd + Hungarian + EMA/pseudo-label)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -347,7 +353,9 @@ def main():
                        "parallelism": "dp%d image-sharded, grad all-reduce %d fp32 over RCCL" % (world, GRAD_ELEMS)
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+                         if traffic else None,
                          "alg_bytes_per_launch": dom["bytes"], "avg_launch_us": dur_s * 1e6,
                          "launches_timed": dom["launches"]},
             "breakdown_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(stats.items())},
