@@ -122,12 +122,12 @@ def test_fast_path_generic_heads_levels_points(M, L, P):
     ([(17, 9)], 3, 1, "near"),                                  # single level, ragged patches, odd head count
     ([(9, 33), (5, 17), (3, 9), (2, 5), (1, 3)], 8, 4, "wide"), # five levels, samples partly outside
 ])
-@pytest.mark.parametrize("variant", [0, 32])
-def test_encoder_self_attention_backward_vs_oracle(shapes, M, P, mode, variant):
-    """num_query == spatial_size selects the LDS-window backward kernel (variant 0); variant 32 forces the
-    plain kernel on the same inputs.  Both must match the oracle."""
+@pytest.mark.parametrize("variant", [(0, 0), (1, 32)])
+def test_encoder_self_attention_vs_oracle(shapes, M, P, mode, variant):
+    """num_query == spatial_size (+ num_point == 4) selects the LDS-window forward and backward kernels
+    (variant 0); (1, 32) forces the plain kernels on the same inputs.  Both must match the oracle."""
     import semi_detr_amd
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, variant)
+    semi_detr_amd._lib.lib().semidetr_msda_set_variant(*variant)
     rng = np.random.default_rng(len(shapes) * 100 + M + P)
     shp = np.asarray(shapes, np.int64)
     L, N, D = len(shapes), 2, 32
@@ -146,6 +146,7 @@ def test_encoder_self_attention_backward_vs_oracle(shapes, M, P, mode, variant):
     gout = rng.random((N, S, M * D)).astype(np.float32)
     case = (value, shp, loc.astype(np.float32), attn.astype(np.float32), gout)
     out, gv, gl, ga = _run(*case)
+    np.testing.assert_allclose(out, oracle.msda_forward(*case[:4]), rtol=0, atol=F32_OUT_ATOL)
     o_gv, o_gl, o_ga = oracle.msda_backward(*case)
     np.testing.assert_allclose(gv, o_gv, rtol=1e-5, atol=F32_GRAD_ATOL)
     np.testing.assert_allclose(gl, o_gl, rtol=1e-5, atol=F32_GRAD_ATOL)
