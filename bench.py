@@ -297,6 +297,8 @@ def main():
     rank, local_rank, world = dp.init_distributed()
     assert world == max(1, args.gpus) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    if os.environ.get("SEMIDETR_BENCH_SHARE_GPU"):      # test aid: all ranks on cuda:0 (with the gloo backend)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -282,191 +282,6 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Forward for encoder self-attention (num_query == spatial_size, num_point == 4), fp32, D == 32.
-//
-// The plain forward is bound by the vector-memory address path (every sample gathers 4 x 128 B through the
-// L1: 1.45 GB per 800x1333 image, ~21 TB/s achieved of the ~39 TB/s the 256 TAs can move).  In the encoder a
-// patch of neighbouring query pixels samples a small neighbourhood of every level, so: a 256-thread
-// workgroup takes an 8 x 8 patch of query pixels of one level and one head and, per sampling level, stages a
-// 16 x 16 window of value rows (32 KB, zero-filled outside the level = the op's zero padding) into LDS with
-// fully coalesced row loads, then serves the bilinear corners from LDS (ds_read_b128, 4x the L1 rate).
-// The window is placed from the patch geometry alone (where the patch's own pixels map to on that level);
-// corners that fall outside it are fetched from global memory exactly as the plain kernel does, so results
-// do not depend on the sampling pattern -- only the speed does.
-// ---------------------------------------------------------------------------------------------
-constexpr int kFT = 8, kFTQ = kFT * kFT;            // query patch 8 x 8
-constexpr int kFW = 16, kFWR = kFW * kFW;           // value window 16 x 16 rows per level
-
-struct FwdLevel {           // per-level constants of the window pass (all wave-uniform)
-    int H, W, st, y0, x0;
-};
-
-__device__ __forceinline__ FwdLevel fwd_level(const int64_t *shapes, const int64_t *starts, int l, float pcy,
-                                              float pcx)
-{
-    FwdLevel v;
-    v.H = (int)shapes[2 * l];
-    v.W = (int)shapes[2 * l + 1];
-    v.st = (int)starts[l];
-    v.y0 = (int)floorf(pcy * v.H - 0.5f) - kFW / 2 + 1;
-    v.x0 = (int)floorf(pcx * v.W - 0.5f) - kFW / 2 + 1;
-    return v;
-}
-
-__global__ __launch_bounds__(256) void msda_fwd_d32_win(
-    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
-    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int tiles_bound,
-    float *__restrict__ out)
-{
-    static_assert(kFTQ * 4 == 256, "one (query, point) sample per thread");
-    __shared__ float4 win[(kFWR + 1) * 8];    // [row][8 x float4]; row kFWR stays all-zero
-    __shared__ float4 rec_w[kFTQ * 4];        // corner weights x attention weight
-    __shared__ int4 rec_i[kFTQ * 4];          // {wy, wx, global offset of the top-left corner, valid bits}
-
-    constexpr int P = 4;
-    const int Lq = S, LP = L * P, rs = M * kD;
-    const int b = blockIdx.x;
-    const int m = b % M;
-    const int slot = (b / M) % tiles_bound, n = (b / M) / tiles_bound;
-    const int tid = threadIdx.x, g = tid >> 3, j = tid & 7;
-    const float *vb = value + ((int64_t)n * S * M + m) * kD + 4 * j;
-    if (tid < 8) win[kFWR * 8 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    for (int tile = slot;; tile += tiles_bound) {
-        int lq = -1, acc_t = 0, ntx = 1, Hq = 0, Wq = 0, stq = 0;
-        for (int l = 0; l < L; ++l) {
-            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-            const int nx = (W + kFT - 1) / kFT, nt = ((H + kFT - 1) / kFT) * nx;
-            if (tile < acc_t + nt) { lq = l; ntx = nx; Hq = H; Wq = W; stq = (int)starts[l]; break; }
-            acc_t += nt;
-        }
-        if (lq < 0) break;
-        const int ty = (tile - acc_t) / ntx, tx = (tile - acc_t) % ntx;
-        // this thread's sample = (query i, point p) of the patch; its group serves queries g and g + 32
-        const int i = tid >> 2, p = tid & 3;
-        const int qy = ty * kFT + i / kFT, qx = tx * kFT + i % kFT;
-        const int q = (qy < Hq && qx < Wq) ? stq + qy * Wq + qx : -1;
-        const int64_t srow = q >= 0 ? ((int64_t)n * Lq + q) * M + m : 0;
-        // patch centre in normalised coordinates (pixel centres are (i + 0.5) / size)
-        const float pcy = (ty * kFT + 0.5f * kFT) / (float)Hq, pcx = (tx * kFT + 0.5f * kFT) / (float)Wq;
-        float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-
-        // ---- software pipeline over the levels: window rows and (loc, attn) of level l+1 are fetched into
-        //      registers while level l is being sampled out of LDS
-        FwdLevel lv = fwd_level(shapes, starts, 0, pcy, pcx);
-        float4 wreg[kFWR / 32];
-        float2 xy = make_float2(0.f, 0.f);
-        float aw = 0.f;
-        auto prefetch = [&](const FwdLevel &f, int l) {
-#pragma unroll
-            for (int k = 0; k < kFWR / 32; ++k) {
-                const int row = g + 32 * k;
-                const int y = f.y0 + row / kFW, x = f.x0 + row % kFW;
-                wreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (y >= 0 && y < f.H && x >= 0 && x < f.W)
-                    wreg[k] = *reinterpret_cast<const float4 *>(vb + (int64_t)(f.st + y * f.W + x) * rs);
-            }
-            if (q >= 0) {
-                xy = *reinterpret_cast<const float2 *>(loc + (srow * LP + l * P + p) * 2);
-                aw = attn[srow * LP + l * P + p];
-            }
-        };
-        prefetch(lv, 0);
-        for (int l = 0; l < L; ++l) {
-            __syncthreads();                  // everyone done sampling the previous level / patch
-#pragma unroll
-            for (int k = 0; k < kFWR / 32; ++k) win[(g + 32 * k) * 8 + j] = wreg[k];
-            {
-                int4 ri = make_int4(0, 0, 0, 0);
-                float4 rw = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q >= 0) {
-                    int off[4];
-                    float lw, lh;
-                    if (sample_setup(xy.x, xy.y, lv.H, lv.W, lv.st, rs, off, lw, lh)) {
-                        const float hh = 1.f - lh, hwt = 1.f - lw;
-                        rw = make_float4(aw * (hh * hwt), aw * (hh * lw), aw * (lh * hwt), aw * (lh * lw));
-                        const int h0 = (int)floorf(sub_rn(mul_rn(xy.y, (float)lv.H), 0.5f));
-                        const int w0 = (int)floorf(sub_rn(mul_rn(xy.x, (float)lv.W), 0.5f));
-                        ri = make_int4(h0 - lv.y0, w0 - lv.x0, (lv.st + h0 * lv.W + w0) * rs,
-                                       (off[0] >= 0 ? 1 : 0) | (off[1] >= 0 ? 2 : 0) | (off[2] >= 0 ? 4 : 0) |
-                                           (off[3] >= 0 ? 8 : 0));
-                    }
-                }
-                rec_i[tid] = ri;
-                rec_w[tid] = rw;
-            }
-            const int Wcur = lv.W;
-            if (l + 1 < L) {
-                lv = fwd_level(shapes, starts, l + 1, pcy, pcx);
-                prefetch(lv, l + 1);
-            }
-            __syncthreads();                  // window + records visible
-            // ---- sample: group g serves queries g and g + 32 of the patch.  Main pass is branch-free: a corner
-            //      outside the window reads the all-zero row kFWR and is remembered in `need`.
-            unsigned need = 0;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int r = g + 32 * u;
-#pragma unroll
-                for (int pp = 0; pp < P; ++pp) {
-                    const int4 ri = rec_i[r * P + pp];
-                    const float4 rw = rec_w[r * P + pp];
-                    const int wy = ri.x, wx = ri.y;
-                    float4 v[4];
-#pragma unroll
-                    for (int cidx = 0; cidx < 4; ++cidx) {
-                        const int cy = wy + (cidx >> 1), cx = wx + (cidx & 1);
-                        const bool inw = (unsigned)cy < (unsigned)kFW && (unsigned)cx < (unsigned)kFW;
-                        v[cidx] = win[(inw ? cy * kFW + cx : kFWR) * 8 + j];
-                        if (!inw && (ri.w & (1 << cidx))) need |= 1u << ((u * P + pp) * 4 + cidx);
-                    }
-                    acc[u].x += rw.x * v[0].x + rw.y * v[1].x + rw.z * v[2].x + rw.w * v[3].x;
-                    acc[u].y += rw.x * v[0].y + rw.y * v[1].y + rw.z * v[2].y + rw.w * v[3].y;
-                    acc[u].z += rw.x * v[0].z + rw.y * v[1].z + rw.z * v[2].z + rw.w * v[3].z;
-                    acc[u].w += rw.x * v[0].w + rw.y * v[1].w + rw.z * v[2].w + rw.w * v[3].w;
-                }
-            }
-            // ---- corners that fell outside the window: straight from global memory, four loads in flight
-            while (__any(need != 0)) {
-                float4 gv[4];
-                float gw[4];
-                int gu[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    gv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    gw[t] = 0.f;
-                    gu[t] = 0;
-                    if (need) {
-                        const int bit = __ffs(need) - 1;
-                        need &= need - 1;
-                        const int sidx = bit >> 2, cidx = bit & 3;
-                        const int r = g + 32 * (sidx >> 2);
-                        const int4 ri = rec_i[r * P + (sidx & 3)];
-                        const float4 rw = rec_w[r * P + (sidx & 3)];
-                        gw[t] = cidx == 0 ? rw.x : cidx == 1 ? rw.y : cidx == 2 ? rw.z : rw.w;
-                        gu[t] = sidx >> 2;
-                        gv[t] = *reinterpret_cast<const float4 *>(vb + ri.z + (cidx & 1) * rs + (cidx >> 1) * Wcur * rs);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float w0 = gu[t] == 0 ? gw[t] : 0.f, w1 = gu[t] == 0 ? 0.f : gw[t];
-                    acc[0].x += w0 * gv[t].x; acc[0].y += w0 * gv[t].y; acc[0].z += w0 * gv[t].z; acc[0].w += w0 * gv[t].w;
-                    acc[1].x += w1 * gv[t].x; acc[1].y += w1 * gv[t].y; acc[1].z += w1 * gv[t].z; acc[1].w += w1 * gv[t].w;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int r = g + 32 * u;
-            const int oy = ty * kFT + r / kFT, ox = tx * kFT + r % kFT;
-            if (oy < Hq && ox < Wq)
-                *reinterpret_cast<float4 *>(out + (((int64_t)n * Lq + stq + oy * Wq + ox) * M + m) * kD + 4 * j) = acc[u];
-        }
-    }
-}
-
 // Sum over the 32 lanes of each wavefront half (lane = channel).  After the five steps lanes 16..31 of
 // each half hold the half's total; the writer is lane 16 / 48.
 __device__ __forceinline__ float half32_sum(float x)
@@ -616,7 +431,7 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_d32_win(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn,
     int S, int M, int L, int tiles_bound, float *__restrict__ gvalue, float *__restrict__ gloc,
-    float *__restrict__ gattn, int dbg)
+    float *__restrict__ gattn)
 {
     static_assert(kTQ * kPT == kWinThreads, "one (query, point) sample per thread");
     static_assert(kWR <= 2 * kWinThreads, "scan assigns two counters per thread");
@@ -747,7 +562,7 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_d32_win(
             __syncthreads();
             // ---- gather half (8 lanes x float4 per value row, as in the forward): corner loads, channel
             //      reductions for grad_attn / grad_loc, direct scatter of the out-of-window corners
-            for (int r = g8; r < kTQ && !(dbg & 1); r += kWinThreads / 8) {
+            for (int r = g8; r < kTQ; r += kWinThreads / 8) {
                 if (qidx[r] < 0) continue;
                 const float4 go = *reinterpret_cast<const float4 *>(gtile + r * kD + 4 * j8);
 #pragma unroll
@@ -802,7 +617,7 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_d32_win(
             // ---- scatter half, owner computes.  The bucketed entries are sorted by window row; every half-wave
             //      (lane = channel) walks an equal share of them, keeps the running row sum in a register and
             //      issues ONE full-line global atomic when the row changes.
-            if (!(dbg & 2)) {
+            {
                 const int total = stats[3];
                 const int lo = (int)((int64_t)total * hw / (kWinThreads / 32));
                 const int hi = (int)((int64_t)total * (hw + 1) / (kWinThreads / 32));
@@ -933,16 +748,6 @@ extern "C" int semidetr_msda_forward_f32(void *stream, const float *value, const
         return rc;
     SEMIDETR_REQUIRE(out, SEMIDETR_E_BADARG, "msda_forward: null output");
     hipStream_t st = semidetr::as_stream(stream);
-    if ((Lq == S && P == 4 && g_fwd_variant == 0) || g_fwd_variant == 64) {
-        SEMIDETR_REQUIRE(Lq == S && P == 4, SEMIDETR_E_BADARG,
-                         "msda_forward: the windowed kernel needs num_query == spatial_size and num_point == 4");
-        const int tiles_bound = (S + kFTQ - 1) / kFTQ * 5 / 4 + 4 * L;    // see the backward launcher
-        const int64_t grid_w = (int64_t)N * tiles_bound * M;
-        SEMIDETR_REQUIRE(grid_w < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
-        hipLaunchKernelGGL(msda_fwd_d32_win, dim3((unsigned)grid_w), dim3(256), 0, st, value, spatial_shapes,
-                           level_start, sampling_loc, attn_weight, S, M, L, tiles_bound, out);
-        return semidetr::launch_status("msda_fwd_d32_win");
-    }
     const int split = pick_split(g_fwd_variant % 10, N, Lq, M);
     const int rpb = 32 / split;
     const int tiles = (Lq + rpb - 1) / rpb;
@@ -1003,7 +808,7 @@ extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, c
         SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
         hipLaunchKernelGGL(msda_bwd_d32_win, dim3((unsigned)grid), dim3(kWinThreads), 0, st, grad_out, value,
                            spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, tiles_bound,
-                           grad_value, grad_sampling_loc, grad_attn_weight, g_fwd_variant >= 1000 ? g_fwd_variant - 1000 : 0);
+                           grad_value, grad_sampling_loc, grad_attn_weight);
         return semidetr::launch_status("msda_bwd_d32_win");
     }
     // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles

@@ -124,7 +124,7 @@ def test_fast_path_generic_heads_levels_points(M, L, P):
 ])
 @pytest.mark.parametrize("variant", [(0, 0), (1, 32)])
 def test_encoder_self_attention_vs_oracle(shapes, M, P, mode, variant):
-    """num_query == spatial_size (+ num_point == 4) selects the LDS-window forward and backward kernels
+    """num_query == spatial_size (+ num_point == 4) selects the owner-computes LDS backward kernel
     (variant 0); (1, 32) forces the plain kernels on the same inputs.  Both must match the oracle."""
     import semi_detr_amd
     semi_detr_amd._lib.lib().semidetr_msda_set_variant(*variant)
