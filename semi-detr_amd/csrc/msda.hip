@@ -393,11 +393,102 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
 }
 
 
+// Gather half of the backward on its own (fp32, D == 32): grad_attn_weight and grad_sampling_loc for every
+// sample, NO grad_value scatter.  Same tiling / LDS records / 8-lane x float4 loads as msda_fwd_d32<1>; the
+// three channel sums per sample are 3 DPP steps inside the 8-lane group.  Streams like the forward (no
+// atomics, no per-level barriers), used together with the owner-computes scatter kernel below.
+__global__ __launch_bounds__(256) void msda_bwd_gather_d32(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn,
+    int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ gloc,
+    float *__restrict__ gattn)
+{
+    constexpr int RPB = 32;
+    extern __shared__ float4 smem[];
+    const int LP = L * P, LPP = LP + 1;
+    int4 *rec_off = reinterpret_cast<int4 *>(smem);
+    float4 *rec_p = smem + RPB * LPP;   // {lw, lh, a, level} ; overwritten with {g_attn, g_x, g_y, -}
+    float *lev_w = reinterpret_cast<float *>(smem + 2 * RPB * LPP), *lev_h = lev_w + kMaxLevels;
+
+    const Tile t = tile_of_block(M, tiles_per_image, RPB);
+    const int rs = M * kD;
+    if (threadIdx.x < L) {
+        lev_h[threadIdx.x] = (float)shapes[2 * threadIdx.x];
+        lev_w[threadIdx.x] = (float)shapes[2 * threadIdx.x + 1];
+    }
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int r = s / LP, k = s - r * LP;
+        const int q = t.q0 + r;
+        int off[4] = {-1, -1, -1, -1};
+        const int l = k / P;
+        float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
+        if (q < Lq) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
+            float lw, lh;
+            if (sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh)) {
+                pr.x = lw;
+                pr.y = lh;
+                pr.z = attn[row * LP + k];
+            }
+        }
+        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_p[r * LPP + k] = pr;
+    }
+    __syncthreads();
+
+    const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int q = t.q0 + r;
+    const float *vb = value + ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Lq) go = *reinterpret_cast<const float4 *>(gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j);
+    const int4 *ro = rec_off + r * LPP;
+    float4 *rp = rec_p + r * LPP;
+#pragma unroll 4
+    for (int k = 0; k < LP; ++k) {
+        const int4 o = ro[k];
+        const float4 pr = rp[k];
+        const float lw = pr.x, lh = pr.y, a = pr.z;
+        const int l = __float_as_int(pr.w);
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const float4 v1 = ld4(vb, o.x), v2 = ld4(vb, o.y), v3 = ld4(vb, o.z), v4 = ld4(vb, o.w);
+        const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
+        float pa = go.x * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) +
+                   go.y * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) +
+                   go.z * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) +
+                   go.w * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
+        float px = ga.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) +
+                   ga.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
+                   ga.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) +
+                   ga.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
+        float py = ga.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) +
+                   ga.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
+                   ga.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) +
+                   ga.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
+        pa = group8_sum(pa);
+        px = group8_sum(px);
+        py = group8_sum(py);
+        if (j == 0) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, 0.f);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int rr = s / LP, k = s - rr * LP;
+        const int qq = t.q0 + rr;
+        if (qq >= Lq) continue;
+        const int64_t row = ((int64_t)t.n * Lq + qq) * M + t.m;
+        const float4 res = rec_p[rr * LPP + k];
+        gattn[row * LP + k] = res.x;
+        *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// Backward for encoder self-attention (num_query == spatial_size: the queries ARE the pixels of the
-// multi-scale map), fp32, D == 32, num_point == 4.
+// grad_value for encoder self-attention (num_query == spatial_size: the queries ARE the pixels of the
+// multi-scale map), fp32, D == 32, num_point == 4.  Runs after msda_bwd_gather_d32.
 //
-// The L2 atomic unit is the bottleneck of the plain kernel (4 full-row atomics per sample; measured ceiling
+// The L2 atomic unit is the bottleneck of the plain backward (4 full-row atomics per sample; measured ceiling
 // 10.4 G full-row fp32 atomics/s chip-wide, tools/atomic_probe.hip), but in the encoder neighbouring queries
 // sample neighbouring pixels, so most of those atomics hit the same few rows.  LDS float atomics are no way
 // out: ds_add_f32 runs lane-serially on gfx950 (~97 clk per 32-lane row vs ~9 for ds_add_u32,
@@ -405,43 +496,35 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
 // using only integer LDS atomics:
 //   * a workgroup takes a TH x TW patch of query pixels of one level and one head; grad_out of the patch is
 //     staged in LDS once (128 rows x 128 B);
-//   * per sampling level it defines a WH x WW window of value rows centred on the mean landing position of
-//     the patch's samples (from the data -- no assumption on the learned offsets), and buckets every
-//     (sample, corner) pair that falls inside the window by target row: count (ds_add_rtn_u32) -> exclusive
-//     scan -> fill {corner weight x attention weight, query index};
-//   * each half-wave then owns window rows: it sums  sum_i w_i * grad_out[q_i][c]  from LDS in a register and
-//     issues ONE full-line global atomic per touched row;
-//   * corners outside the window (rare in the encoder) go straight to global memory, so any sampling pattern
-//     is handled correctly; locality only decides the speed.
-// The gather half (corner loads, grad_attn / grad_loc channel reductions) is the same as in the plain kernel.
+//   * per sampling level it places a WH x WW window of value rows where the patch's own pixels map to on that
+//     level, and buckets every (sample, corner) pair that falls inside the window by target row:
+//     count (ds_add_rtn_u32) -> exclusive scan -> fill {corner weight x attention weight, row, query};
+//   * the bucketed entries are sorted by row; every half-wave (lane = channel) walks an equal share of them,
+//     keeps the running row sum  sum_i w_i * grad_out[q_i][c]  in a register and issues ONE full-line global
+//     atomic per row run;
+//   * corners outside the window (rare in the encoder) are put on a miss list and scattered one full-line
+//     atomic each, exactly like the plain kernel -- any sampling pattern is correct, locality only decides speed.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTH = 8, kTW = 16, kTQ = kTH * kTW;       // query patch: 8 x 16 pixels = 128 queries
 constexpr int kWH = 24, kWW = 32, kWR = kWH * kWW;      // window: 24 x 32 value rows = 768 counters
-constexpr int kWinThreads = 512;                        // 8 wavefronts
+constexpr int kWinThreads = 512;                        // 8 wavefronts = 16 half-waves
 constexpr int kPT = 4;                                  // num_point (compile time: one sample per thread)
+constexpr int kNE = kTQ * kPT * 4;                      // corners per (patch, level)
 
-__device__ __forceinline__ int wave_sum_i(int v)
-{
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-    return v;
-}
-
-__global__ __launch_bounds__(kWinThreads) void msda_bwd_d32_win(
-    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn,
-    int S, int M, int L, int tiles_bound, float *__restrict__ gvalue, float *__restrict__ gloc,
-    float *__restrict__ gattn)
+__global__ __launch_bounds__(kWinThreads) void msda_bwd_scatter_d32_win(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int tiles_bound,
+    float *__restrict__ gvalue)
 {
     static_assert(kTQ * kPT == kWinThreads, "one (query, point) sample per thread");
     static_assert(kWR <= 2 * kWinThreads, "scan assigns two counters per thread");
-    __shared__ int4 rec_off[kTQ * kPT];          // corner offsets (or -1)
-    __shared__ float4 rec_p[kTQ * kPT];          // {lw, lh, a, in-window bits}  -> results {g_attn, g_x, g_y, -}
-    __shared__ float2 entries[kTQ * kPT * 4];    // bucketed {weight, window row << 8 | query-in-patch}
+    __shared__ int4 rec_off[kTQ * kPT];          // corner offsets (or -1), needed again for the miss list
+    __shared__ float2 entries[kNE];              // front: bucketed {weight, window row << 8 | query};
+                                                 // back : misses {weight, corner << 16 | sample}
     __shared__ float gtile[kTQ * kD];            // grad_out rows of the patch
     __shared__ int cnt[kWR], start[kWR];
-    __shared__ int qidx[kTQ];
-    __shared__ int stats[4], wsum[kWinThreads / 64];
+    __shared__ int stats2[2][4], wsum[kWinThreads / 64];   // stats double-buffered by level parity: a fast
+                                                           // wavefront may start level l+1 while others still read l's
 
     constexpr int P = kPT;
     const int Lq = S, LP = L * P, rs = M * kD;
@@ -449,11 +532,7 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_d32_win(
     const int m = b % M;
     const int slot = (b / M) % tiles_bound, n = (b / M) / tiles_bound;
     const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
-    const int g8 = tid >> 3, j8 = tid & 7;                    // 8-lane groups of the gather half
-    const int64_t img = ((int64_t)n * S * M + m) * kD;
-    const float *vb4 = value + img + 4 * j8;                  // gather half: lane = 4 channels
-    float *gvb4 = gvalue + img + 4 * j8;
-    float *gvb = gvalue + img + c;                            // scatter half: lane = channel
+    float *gvb = gvalue + ((int64_t)n * S * M + m) * kD + c;     // lane = channel
 
     for (int tile = slot;; tile += tiles_bound) {
         // ---- which patch of which level is tile number `tile`? (uniform across the workgroup)
@@ -466,69 +545,59 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_d32_win(
         }
         if (lq < 0) break;
         const int ty = (tile - acc) / ntx, tx = (tile - acc) % ntx;
+        // this thread's sample = (query i, point p) of the patch
+        const int i = tid / P, p = tid - i * P;
+        const int qy = ty * kTH + i / kTW, qx = tx * kTW + i % kTW;
+        const int q = (qy < Hq && qx < Wq) ? stq + qy * Wq + qx : -1;
+        const int64_t srow = q >= 0 ? ((int64_t)n * Lq + q) * M + m : 0;
+        // patch centre in normalised coordinates (pixel centres are (i + 0.5) / size)
+        const float pcy = (ty * kTH + 0.5f * kTH) / (float)Hq, pcx = (tx * kTW + 0.5f * kTW) / (float)Wq;
         __syncthreads();                      // previous patch fully done before its LDS state is reused
-        if (tid < kTQ) {
-            const int y = ty * kTH + tid / kTW, x = tx * kTW + tid % kTW;
-            qidx[tid] = (y < Hq && x < Wq) ? stq + y * Wq + x : -1;
-        }
-        __syncthreads();
         for (int r = hw; r < kTQ; r += kWinThreads / 32) {      // stage grad_out of the patch
-            const int q = qidx[r];
-            gtile[r * kD + c] = q >= 0 ? gout[(((int64_t)n * Lq + q) * M + m) * kD + c] : 0.f;
+            const int ry = ty * kTH + r / kTW, rx = tx * kTW + r % kTW;
+            gtile[r * kD + c] =
+                (ry < Hq && rx < Wq) ? gout[(((int64_t)n * Lq + stq + ry * Wq + rx) * M + m) * kD + c] : 0.f;
         }
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            // window: where the patch centre maps to on this level, minus half the window
+            const int y0 = (int)floorf(pcy * H - 0.5f) - kWH / 2 + 1;
+            const int x0 = (int)floorf(pcx * W - 0.5f) - kWW / 2 + 1;
+            int *stats = stats2[l & 1];
             if (tid < 4) stats[tid] = 0;
-            for (int i = tid; i < kWR; i += kWinThreads) cnt[i] = 0;
-            __syncthreads();
-            // ---- this thread's sample: geometry + landing statistics (one LDS atomic per wavefront)
-            const int i = tid / P, p = tid - i * P;
-            const int q = qidx[i];
+            for (int k = tid; k < kWR; k += kWinThreads) cnt[k] = 0;
+            // ---- this thread's sample geometry
             int off[4] = {-1, -1, -1, -1};
             float lw = 0.f, lh = 0.f, a = 0.f;
             int h0 = 0, w0 = 0;
-            bool inside = false;
             if (q >= 0) {
-                const int64_t row = ((int64_t)n * Lq + q) * M + m;
                 const int k = l * P + p;
-                const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
-                inside = sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh);
-                if (inside) {
-                    a = attn[row * LP + k];
+                const float2 xy = *reinterpret_cast<const float2 *>(loc + (srow * LP + k) * 2);
+                if (sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh)) {
+                    a = attn[srow * LP + k];
                     // the top-left corner (h0, w0) exactly as sample_setup derived it
                     h0 = (int)floorf(sub_rn(mul_rn(xy.y, (float)H), 0.5f));
                     w0 = (int)floorf(sub_rn(mul_rn(xy.x, (float)W), 0.5f));
                 }
             }
-            {
-                const int sh = wave_sum_i(inside ? h0 : 0), sw = wave_sum_i(inside ? w0 : 0);
-                const int sc = __popcll(__ballot(inside));
-                if (lane == 0 && sc) { atomicAdd(&stats[0], sh); atomicAdd(&stats[1], sw); atomicAdd(&stats[2], sc); }
-            }
-            __syncthreads();
-            // window origin: mean top-left corner minus half the window
-            int y0 = 0, x0 = 0;
-            {
-                const int n_in = stats[2];
-                if (n_in > 0) {
-                    y0 = (int)floorf((float)stats[0] / (float)n_in) - kWH / 2 + 1;
-                    x0 = (int)floorf((float)stats[1] / (float)n_in) - kWW / 2 + 1;
-                }
-            }
-            // ---- bucket the in-window corners by window row: count
+            __syncthreads();                  // counters zeroed, previous level's walk finished
+            // ---- bucket the in-window corners by window row (count), list the others as misses
             const int wy = h0 - y0, wx = w0 - x0;
             const bool in_y0 = (unsigned)wy < (unsigned)kWH, in_y1 = (unsigned)(wy + 1) < (unsigned)kWH;
             const bool in_x0 = (unsigned)wx < (unsigned)kWW, in_x1 = (unsigned)(wx + 1) < (unsigned)kWW;
             const int wi = wy * kWW + wx;
-            const bool b1 = off[0] >= 0 && in_y0 && in_x0, b2 = off[1] >= 0 && in_y0 && in_x1;
-            const bool b3 = off[2] >= 0 && in_y1 && in_x0, b4 = off[3] >= 0 && in_y1 && in_x1;
-            int r1 = 0, r2 = 0, r3 = 0, r4 = 0;
-            if (b1) r1 = atomicAdd(&cnt[wi], 1);
-            if (b2) r2 = atomicAdd(&cnt[wi + 1], 1);
-            if (b3) r3 = atomicAdd(&cnt[wi + kWW], 1);
-            if (b4) r4 = atomicAdd(&cnt[wi + kWW + 1], 1);
+            const float hh = 1.f - lh, hwt = 1.f - lw;
+            const float cw[4] = {hh * hwt * a, hh * lw * a, lh * hwt * a, lh * lw * a};
+            const bool inw[4] = {in_y0 && in_x0, in_y0 && in_x1, in_y1 && in_x0, in_y1 && in_x1};
+            const int wrow[4] = {wi, wi + 1, wi + kWW, wi + kWW + 1};
+            int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                if (off[cidx] < 0) continue;
+                if (inw[cidx]) rank[cidx] = atomicAdd(&cnt[wrow[cidx]], 1);
+                else entries[kNE - 1 - atomicAdd(&stats[1], 1)] = make_float2(cw[cidx], __int_as_float((cidx << 16) | tid));
+            }
             rec_off[tid] = make_int4(off[0], off[1], off[2], off[3]);
-            rec_p[tid] = make_float4(lw, lh, a, __int_as_float((b1 ? 1 : 0) | (b2 ? 2 : 0) | (b3 ? 4 : 0) | (b4 ? 8 : 0)));
             __syncthreads();
             // ---- exclusive scan of the kWR counters -> start[]  (thread t owns counters 2t, 2t+1)
             {
@@ -548,75 +617,16 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_d32_win(
                 const int excl = base + incl - v;
                 if (j0 < kWR) start[j0] = excl;
                 if (j0 + 1 < kWR) start[j0 + 1] = excl + c0;
-                if (tid == kWinThreads - 1) stats[3] = excl + v;            // total number of entries
+                if (tid == kWinThreads - 1) stats[3] = excl + v;            // total number of bucketed entries
             }
             __syncthreads();
             // ---- fill the buckets
-            {
-                const float hh = 1.f - lh, hwt = 1.f - lw;
-                if (b1) entries[start[wi] + r1] = make_float2(hh * hwt * a, __int_as_float((wi << 8) | i));
-                if (b2) entries[start[wi + 1] + r2] = make_float2(hh * lw * a, __int_as_float(((wi + 1) << 8) | i));
-                if (b3) entries[start[wi + kWW] + r3] = make_float2(lh * hwt * a, __int_as_float(((wi + kWW) << 8) | i));
-                if (b4) entries[start[wi + kWW + 1] + r4] = make_float2(lh * lw * a, __int_as_float(((wi + kWW + 1) << 8) | i));
-            }
-            __syncthreads();
-            // ---- gather half (8 lanes x float4 per value row, as in the forward): corner loads, channel
-            //      reductions for grad_attn / grad_loc, direct scatter of the out-of-window corners
-            for (int r = g8; r < kTQ; r += kWinThreads / 8) {
-                if (qidx[r] < 0) continue;
-                const float4 go = *reinterpret_cast<const float4 *>(gtile + r * kD + 4 * j8);
 #pragma unroll
-                for (int pp = 0; pp < kPT; ++pp) {
-                    const int s = r * kPT + pp;
-                    const int4 o = rec_off[s];
-                    const float4 pr = rec_p[s];
-                    const float4 v1 = ld4(vb4, o.x), v2 = ld4(vb4, o.y), v3 = ld4(vb4, o.z), v4 = ld4(vb4, o.w);
-                    const float slw = pr.x, slh = pr.y, sa = pr.z;
-                    const int inwin = __float_as_int(pr.w);
-                    const float hh = 1.f - slh, hwt = 1.f - slw;
-                    const float w1 = hh * hwt, w2 = hh * slw, w3 = slh * hwt, w4 = slh * slw;
-                    const float4 ga = make_float4(go.x * sa, go.y * sa, go.z * sa, go.w * sa);
-                    if (o.x >= 0 && !(inwin & 1)) {
-                        float *pg = gvb4 + o.x;
-                        fp_atomic_add(pg, w1 * ga.x); fp_atomic_add(pg + 1, w1 * ga.y);
-                        fp_atomic_add(pg + 2, w1 * ga.z); fp_atomic_add(pg + 3, w1 * ga.w);
-                    }
-                    if (o.y >= 0 && !(inwin & 2)) {
-                        float *pg = gvb4 + o.y;
-                        fp_atomic_add(pg, w2 * ga.x); fp_atomic_add(pg + 1, w2 * ga.y);
-                        fp_atomic_add(pg + 2, w2 * ga.z); fp_atomic_add(pg + 3, w2 * ga.w);
-                    }
-                    if (o.z >= 0 && !(inwin & 4)) {
-                        float *pg = gvb4 + o.z;
-                        fp_atomic_add(pg, w3 * ga.x); fp_atomic_add(pg + 1, w3 * ga.y);
-                        fp_atomic_add(pg + 2, w3 * ga.z); fp_atomic_add(pg + 3, w3 * ga.w);
-                    }
-                    if (o.w >= 0 && !(inwin & 8)) {
-                        float *pg = gvb4 + o.w;
-                        fp_atomic_add(pg, w4 * ga.x); fp_atomic_add(pg + 1, w4 * ga.y);
-                        fp_atomic_add(pg + 2, w4 * ga.z); fp_atomic_add(pg + 3, w4 * ga.w);
-                    }
-                    float pa = go.x * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) +
-                               go.y * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) +
-                               go.z * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) +
-                               go.w * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
-                    float px = ga.x * (hh * (v2.x - v1.x) + slh * (v4.x - v3.x)) +
-                               ga.y * (hh * (v2.y - v1.y) + slh * (v4.y - v3.y)) +
-                               ga.z * (hh * (v2.z - v1.z) + slh * (v4.z - v3.z)) +
-                               ga.w * (hh * (v2.w - v1.w) + slh * (v4.w - v3.w));
-                    float py = ga.x * (hwt * (v3.x - v1.x) + slw * (v4.x - v2.x)) +
-                               ga.y * (hwt * (v3.y - v1.y) + slw * (v4.y - v2.y)) +
-                               ga.z * (hwt * (v3.z - v1.z) + slw * (v4.z - v2.z)) +
-                               ga.w * (hwt * (v3.w - v1.w) + slw * (v4.w - v2.w));
-                    pa = group8_sum(pa);
-                    px = group8_sum(px);
-                    py = group8_sum(py);
-                    if (j8 == 0) rec_p[s] = make_float4(pa, (float)W * px, (float)H * py, 0.f);
-                }
-            }
-            // ---- scatter half, owner computes.  The bucketed entries are sorted by window row; every half-wave
-            //      (lane = channel) walks an equal share of them, keeps the running row sum in a register and
-            //      issues ONE full-line global atomic when the row changes.
+            for (int cidx = 0; cidx < 4; ++cidx)
+                if (off[cidx] >= 0 && inw[cidx])
+                    entries[start[wrow[cidx]] + rank[cidx]] = make_float2(cw[cidx], __int_as_float((wrow[cidx] << 8) | i));
+            __syncthreads();
+            // ---- owner computes: every half-wave walks an equal share of the row-sorted entries
             {
                 const int total = stats[3];
                 const int lo = (int)((int64_t)total * hw / (kWinThreads / 32));
@@ -648,14 +658,17 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_d32_win(
                 }
                 if (cur >= 0) fp_atomic_add(gvb + (int64_t)(st + (y0 + cur / kWW) * W + x0 + cur % kWW) * rs, accv);
             }
-            __syncthreads();
-            // ---- grad_attn_weight / grad_sampling_loc of this level (thread = sample, as above)
-            if (q >= 0) {
-                const int64_t row = ((int64_t)n * Lq + q) * M + m;
-                const int k = l * P + p;
-                const float4 res = rec_p[tid];
-                gattn[row * LP + k] = res.x;
-                *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
+            // ---- misses: one full-line atomic per (sample, corner), as the plain kernel does
+            {
+                const int nmiss = stats[1];
+                for (int mi = hw; mi < nmiss; mi += kWinThreads / 32) {
+                    const float2 en = entries[kNE - 1 - mi];
+                    const int pk = __float_as_int(en.y);
+                    const int sidx = pk & 0xffff, cidx = pk >> 16;
+                    const int4 o = rec_off[sidx];
+                    const int oc = cidx == 0 ? o.x : cidx == 1 ? o.y : cidx == 2 ? o.z : o.w;
+                    fp_atomic_add(gvb + oc, en.x * gtile[(sidx / P) * kD + c]);
+                }
             }
         }
     }
@@ -806,10 +819,17 @@ extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, c
         const int tiles_bound = (S + kTQ - 1) / kTQ * 5 / 4 + 4 * L;
         const int64_t grid = (int64_t)N * tiles_bound * M;
         SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
-        hipLaunchKernelGGL(msda_bwd_d32_win, dim3((unsigned)grid), dim3(kWinThreads), 0, st, grad_out, value,
-                           spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, tiles_bound,
-                           grad_value, grad_sampling_loc, grad_attn_weight);
-        return semidetr::launch_status("msda_bwd_d32_win");
+        {   // gather half: grad_attn_weight / grad_sampling_loc, streams like the forward
+            const int gt = (Lq + 31) / 32;
+            const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
+            hipLaunchKernelGGL(msda_bwd_gather_d32, dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
+                               grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq,
+                               P, gt, grad_sampling_loc, grad_attn_weight);
+            if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
+        }
+        hipLaunchKernelGGL(msda_bwd_scatter_d32_win, dim3((unsigned)grid), dim3(kWinThreads), 0, st, grad_out,
+                           spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, tiles_bound, grad_value);
+        return semidetr::launch_status("msda_bwd_scatter_d32_win");
     }
     // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles
     int rpb = (int64_t)N * M * ((Lq + 31) / 32) >= 1024 ? 32 : 8;
