@@ -445,32 +445,49 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
     if (q < Lq) go = *reinterpret_cast<const float4 *>(gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j);
     const int4 *ro = rec_off + r * LPP;
     float4 *rp = rec_p + r * LPP;
-#pragma unroll 4
-    for (int k = 0; k < LP; ++k) {
-        const int4 o = ro[k];
-        const float4 pr = rp[k];
-        const float lw = pr.x, lh = pr.y, a = pr.z;
-        const int l = __float_as_int(pr.w);
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        const float4 v1 = ld4(vb, o.x), v2 = ld4(vb, o.y), v3 = ld4(vb, o.z), v4 = ld4(vb, o.w);
-        const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
-        float pa = go.x * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) +
-                   go.y * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) +
-                   go.z * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) +
-                   go.w * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
-        float px = ga.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) +
-                   ga.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
-                   ga.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) +
-                   ga.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
-        float py = ga.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) +
-                   ga.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
-                   ga.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) +
-                   ga.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
-        pa = group8_sum(pa);
-        px = group8_sum(px);
-        py = group8_sum(py);
-        if (j == 0) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, 0.f);
+    // Batches of kGU samples, unrolled by hand: the result store into rec_p would otherwise keep the compiler
+    // from hoisting the next samples' record reads / corner loads above it (4 * kGU loads in flight per lane; measured on MI355X at the encoder shape: kGU 1 / 2 / 4 -> 438 / 508 / 643 us, so 1).
+    constexpr int kGU = 1;
+    for (int k0 = 0; k0 < LP; k0 += kGU) {
+        int4 o[kGU];
+        float4 pr[kGU], v[kGU][4];
+#pragma unroll
+        for (int u = 0; u < kGU; ++u) {
+            const int k = min(k0 + u, LP - 1);
+            o[u] = ro[k];
+            pr[u] = rp[k];
+        }
+#pragma unroll
+        for (int u = 0; u < kGU; ++u) {
+            v[u][0] = ld4(vb, o[u].x); v[u][1] = ld4(vb, o[u].y);
+            v[u][2] = ld4(vb, o[u].z); v[u][3] = ld4(vb, o[u].w);
+        }
+#pragma unroll
+        for (int u = 0; u < kGU; ++u) {
+            if (k0 + u >= LP) break;
+            const float lw = pr[u].x, lh = pr[u].y, a = pr[u].z;
+            const int l = __float_as_int(pr[u].w);
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+            const float4 v1 = v[u][0], v2 = v[u][1], v3 = v[u][2], v4 = v[u][3];
+            const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
+            float pa = go.x * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) +
+                       go.y * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) +
+                       go.z * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) +
+                       go.w * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
+            float px = ga.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) +
+                       ga.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
+                       ga.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) +
+                       ga.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
+            float py = ga.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) +
+                       ga.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
+                       ga.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) +
+                       ga.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
+            pa = group8_sum(pa);
+            px = group8_sum(px);
+            py = group8_sum(py);
+            if (j == 0) rp[k0 + u] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, 0.f);
+        }
     }
     __syncthreads();
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
@@ -771,7 +788,7 @@ extern "C" int semidetr_msda_forward_f32(void *stream, const float *value, const
     hipLaunchKernelGGL((msda_fwd_d32<SP, UN>), dim3((unsigned)grid), dim3(256), lds, st, value,             \
                        spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq, P, tiles, out)
     const int unroll = g_fwd_variant >= 10 && g_fwd_variant < 100 ? g_fwd_variant / 10 : 4;
-    if (split == 1) { if (unroll == 2) LAUNCH_FWD(1, 2); else if (unroll == 8) LAUNCH_FWD(1, 8); else LAUNCH_FWD(1, 4); }
+    if (split == 1) { if (unroll == 2) LAUNCH_FWD(1, 2); else if (unroll == 1) LAUNCH_FWD(1, 1); else LAUNCH_FWD(1, 4); }
     else if (split == 2) LAUNCH_FWD(2, 4);
     else LAUNCH_FWD(4, 4);
 #undef LAUNCH_FWD
