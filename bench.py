@@ -259,9 +259,9 @@ def microbench(dev, iters=200, warm=20):
 
 def cpu_baseline():
     """The oracle (a C port of the reference arithmetic; the reference itself has no native CPU path --
-    ms_deform_attn_cpu.cpp:26,39 only raises) timed on this box's host cores on a bounded sample: one image
-    of the encoder shape and one of the decoder shape, forward (OpenMP, all cores) + backward (1 core).
-    Extrapolated linearly in batch to the launches of one step -> images/s."""
+    ms_deform_attn_cpu.cpp:26,39 only raises) timed on this box's host cores with OpenMP on a bounded sample:
+    one image of the encoder shape and one of the decoder shape, forward + backward (backward scatter by
+    `omp atomic`).  Extrapolated linearly in batch to the launches of one step -> images/s."""
     import oracle
     cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
@@ -273,14 +273,22 @@ def cpu_baseline():
         a = rng.random((1, lq, M, L, P)).astype(np.float32)
         a /= a.sum((-1, -2), keepdims=True)
         go = rng.random((1, lq, M * D)).astype(np.float32)
-        t0 = time.perf_counter(); oracle.msda_forward(value, shapes, loc, a); t[kind + "_f"] = time.perf_counter() - t0
-        t0 = time.perf_counter(); oracle.msda_backward(value, shapes, loc, a, go); t[kind + "_b"] = time.perf_counter() - t0
+        oracle.msda_forward(value, shapes, loc, a)                      # warm the thread pool / page in
+        reps = 3 if kind == "enc" else 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.msda_forward(value, shapes, loc, a)
+        t[kind + "_f"] = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle.msda_backward(value, shapes, loc, a, go, parallel=True)
+        t[kind + "_b"] = (time.perf_counter() - t0) / reps
     fwd_imgs, bwd_imgs = 6 * (1 + 4 * 4), 6 * (1 + 4)          # image-layers per step (enc and dec alike)
     step_s = fwd_imgs * (t["enc_f"] + t["dec_f"]) + bwd_imgs * (t["enc_b"] + t["dec_b"])
     return {"value": IMAGES_PER_GPU / step_s, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle msda fwd(OpenMP, %d threads)+bwd(1 thread) on 1 encoder-shape image (Lq=22223) and "
-                      "1 decoder-shape image (Lq=1100), %.2f s measured, extrapolated to the step's 102 fwd / 30 bwd "
-                      "image-layers; matcher/EMA excluded" % (cores, sum(t.values())),
+            "sample": "oracle (C + OpenMP, %d threads) msda fwd+bwd on 1 encoder-shape image (Lq=22223, 3 reps) and "
+                      "1 decoder-shape image (Lq=1100, 20 reps), extrapolated to the step's 102 fwd / 30 bwd "
+                      "image-layers; matcher/EMA excluded" % cores,
             "enc_fwd_s": t["enc_f"], "enc_bwd_s": t["enc_b"], "dec_fwd_s": t["dec_f"], "dec_bwd_s": t["dec_b"]}
 
 

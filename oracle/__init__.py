@@ -68,8 +68,10 @@ def msda_forward(value, shapes, loc, attn, level_start=None):
     return out
 
 
-def msda_backward(value, shapes, loc, attn, grad_out, level_start=None):
-    """-> grad_value, grad_loc, grad_attn (same shapes/dtype as value, loc, attn)."""
+def msda_backward(value, shapes, loc, attn, grad_out, level_start=None, parallel=False):
+    """-> grad_value, grad_loc, grad_attn (same shapes/dtype as value, loc, attn).
+    parallel=True uses all host cores with an atomic scatter (summation order not deterministic): for the
+    cpu_baseline timing only; parity tests use the serial, deterministic default."""
     dt = np.float64 if value.dtype == np.float64 else np.float32
     value, loc, attn, grad_out = _c(value, dt), _c(loc, dt), _c(attn, dt), _c(grad_out, dt)
     shapes = _c(shapes, np.int64)
@@ -77,7 +79,8 @@ def msda_backward(value, shapes, loc, attn, grad_out, level_start=None):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     gv, gl, ga = np.empty_like(value), np.empty_like(loc), np.empty_like(attn)
-    fn = lib().msda_oracle_backward_f64 if dt == np.float64 else lib().msda_oracle_backward_f32
+    name = "msda_oracle_backward_" + ("omp_" if parallel else "") + ("f64" if dt == np.float64 else "f32")
+    fn = getattr(lib(), name)
     fn(_p(value), _p(shapes), _p(starts), _p(loc), _p(attn), _p(grad_out), N, S, M, D, L, Lq, P,
        _p(gv), _p(gl), _p(ga))
     return gv, gl, ga
