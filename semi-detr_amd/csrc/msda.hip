@@ -528,16 +528,15 @@ constexpr int kWinThreads = 512;                        // 8 wavefronts = 16 hal
 constexpr int kPT = 4;                                  // num_point (compile time: one sample per thread)
 constexpr int kNE = kTQ * kPT * 4;                      // corners per (patch, level)
 
-__global__ __launch_bounds__(kWinThreads) void msda_bwd_scatter_d32_win(
+__global__ __launch_bounds__(kWinThreads, 6) void msda_bwd_scatter_d32_win(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int tiles_bound,
     float *__restrict__ gvalue)
 {
     static_assert(kTQ * kPT == kWinThreads, "one (query, point) sample per thread");
     static_assert(kWR <= 2 * kWinThreads, "scan assigns two counters per thread");
-    __shared__ int4 rec_off[kTQ * kPT];          // corner offsets (or -1), needed again for the miss list
     __shared__ float2 entries[kNE];              // front: bucketed {weight, window row << 8 | query};
-                                                 // back : misses {weight, corner << 16 | sample}
+                                                 // back : misses {weight, query << 25 | pixel index}
     __shared__ float gtile[kTQ * kD];            // grad_out rows of the patch
     __shared__ int cnt[kWR], start[kWR];
     __shared__ int stats2[2][4], wsum[kWinThreads / 64];   // stats double-buffered by level parity: a fast
@@ -612,9 +611,10 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_scatter_d32_win(
             for (int cidx = 0; cidx < 4; ++cidx) {
                 if (off[cidx] < 0) continue;
                 if (inw[cidx]) rank[cidx] = atomicAdd(&cnt[wrow[cidx]], 1);
-                else entries[kNE - 1 - atomicAdd(&stats[1], 1)] = make_float2(cw[cidx], __int_as_float((cidx << 16) | tid));
+                else   // off = pixel index * rs: keep the pixel index (< 2^25, checked by the launcher) + the query
+                    entries[kNE - 1 - atomicAdd(&stats[1], 1)] =
+                        make_float2(cw[cidx], __int_as_float((i << 25) | (off[cidx] / rs)));
             }
-            rec_off[tid] = make_int4(off[0], off[1], off[2], off[3]);
             __syncthreads();
             // ---- exclusive scan of the kWR counters -> start[]  (thread t owns counters 2t, 2t+1)
             {
@@ -681,10 +681,8 @@ __global__ __launch_bounds__(kWinThreads) void msda_bwd_scatter_d32_win(
                 for (int mi = hw; mi < nmiss; mi += kWinThreads / 32) {
                     const float2 en = entries[kNE - 1 - mi];
                     const int pk = __float_as_int(en.y);
-                    const int sidx = pk & 0xffff, cidx = pk >> 16;
-                    const int4 o = rec_off[sidx];
-                    const int oc = cidx == 0 ? o.x : cidx == 1 ? o.y : cidx == 2 ? o.z : o.w;
-                    fp_atomic_add(gvb + oc, en.x * gtile[(sidx / P) * kD + c]);
+                    const int64_t oc = (int64_t)(pk & 0x1ffffff) * rs;
+                    fp_atomic_add(gvb + oc, en.x * gtile[((unsigned)pk >> 25) * kD + c]);
                 }
             }
         }
@@ -827,9 +825,9 @@ extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, c
     hipStream_t st = semidetr::as_stream(stream);
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * D, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    if ((Lq == S && P == kPT && g_bwd_variant == 0) || g_bwd_variant == 64) {
-        SEMIDETR_REQUIRE(Lq == S && P == kPT, SEMIDETR_E_BADARG,
-                         "msda_backward: the windowed kernel needs num_query == spatial_size and num_point == 4");
+    if ((Lq == S && P == kPT && S < (1 << 25) && g_bwd_variant == 0) || g_bwd_variant == 64) {
+        SEMIDETR_REQUIRE(Lq == S && P == kPT && S < (1 << 25), SEMIDETR_E_BADARG,
+                         "msda_backward: the windowed kernel needs num_query == spatial_size < 2^25 and num_point == 4");
         // patches are enumerated on the device (the level table lives in device memory); a workgroup takes
         // patches slot, slot + tiles_bound, ... so any bound >= 1 is correct; this one covers the usual
         // pyramids (sum of ceil(H/8)*ceil(W/16) <= S/128 * 1.25 + 4 per level) in a single round.
