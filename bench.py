@@ -240,6 +240,8 @@ def microbench(dev, iters=200, warm=20):
                      ("bwd", lambda: MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn, gout, 64))):
         for _ in range(warm):
             fn()
+        # (a) eager launches from Python: includes the host cost of each call (allocation + ctypes), which at
+        #     this size is larger than the kernel itself
         ts = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -249,7 +251,32 @@ def microbench(dev, iters=200, warm=20):
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3 / (iters // 5))
+        res[name + "_eager_us"] = float(np.median(ts))
+        # (b) the same launches captured once in a HIP graph and replayed: device time per call, which is
+        #     what a training step sees (launches are queued ahead of the GPU)
+        per_graph = 20
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(graph):
+            for _ in range(per_graph):
+                fn()
+        graph.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / (5 * per_graph))
         res[name + "_us"] = float(np.median(ts))
+        del graph
     res["fwd_bwd_us"] = res["fwd_us"] + res["bwd_us"]
     b = msda_alg_bytes(N, Lq, False) + msda_alg_bytes(N, Lq, True)
     res["alg_bytes"] = b

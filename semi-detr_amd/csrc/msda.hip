@@ -210,8 +210,40 @@ __device__ __forceinline__ Tile tile_of_block(int M, int tiles_per_image, int ro
     return t;
 }
 
+// Encoder self-attention (num_query == spatial_size: query i IS pixel i of the multi-scale map): instead of
+// 32 consecutive pixels (a 32 x 1 strip) a workgroup can take a PH x PW patch of one level -- its samples
+// then land in a (PH + margin) x (PW + margin) neighbourhood on every level instead of a long thin one, which
+// roughly halves the distinct value rows a workgroup pulls through its L1.  Patches are enumerated on the
+// device because the level table lives in device memory; `tile` indexes them level by level.
+struct Patch {
+    int Hq, Wq, stq, y0, x0;     // level of the patch's queries and its top-left pixel; Hq == 0: no such patch
+};
+template <int PH, int PW>
+__device__ __forceinline__ Patch find_patch(int tile, const int64_t *shapes, const int64_t *starts, int L)
+{
+    Patch p = {0, 0, 0, 0, 0};
+    int acc = 0;
+    for (int l = 0; l < L; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const int nx = (W + PW - 1) / PW, nt = ((H + PH - 1) / PH) * nx;
+        if (tile < acc + nt) {
+            p.Hq = H; p.Wq = W; p.stq = (int)starts[l];
+            p.y0 = ((tile - acc) / nx) * PH; p.x0 = ((tile - acc) % nx) * PW;
+            return p;
+        }
+        acc += nt;
+    }
+    return p;
+}
+template <int PW>
+__device__ __forceinline__ int patch_query(const Patch &p, int r)      // r-th query of the patch or -1
+{
+    const int y = p.y0 + r / PW, x = p.x0 + r % PW;
+    return (y < p.Hq && x < p.Wq) ? p.stq + y * p.Wq + x : -1;
+}
+
 // SPLIT = number of 8-lane groups that share one (q) row; each takes samples k = part, part+SPLIT, ...
-template <int SPLIT, int UNROLL>
+template <int SPLIT, int UNROLL, int PATCH = 0>
 __global__ __launch_bounds__(256) void msda_fwd_d32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq, int P,
@@ -223,16 +255,28 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     int4 *rec_off = reinterpret_cast<int4 *>(smem);
     float4 *rec_w = smem + RPB * LPP;
 
-    const Tile t = tile_of_block(M, tiles_per_image, RPB);
+    Tile t = tile_of_block(M, tiles_per_image, RPB);
     const int rs = M * kD;
+    constexpr int PH = PATCH / 100, PW = PATCH % 100;
+    static_assert(PATCH == 0 || (PH * PW == RPB && SPLIT == 1), "a patch holds exactly the workgroup's rows");
+    Patch pt = {0, 0, 0, 0, 0};
+    // PATCH: tiles_per_image is only a sizing hint for the grid -- a workgroup takes patches slot, slot + hint,
+    // ... until the pyramid is exhausted, so any hint >= 1 is correct (the level table is device memory).
+    for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
+    if (PATCH) {
+        pt = find_patch<PH ? PH : 1, PW ? PW : 1>(tile, shapes, starts, L);
+        if (pt.Hq == 0) return;
+        __syncthreads();      // previous patch done with the LDS records
+    }
+    auto query_of = [&](int r) { return PATCH ? patch_query<PW ? PW : 1>(pt, r) : (t.q0 + r < Lq ? t.q0 + r : -1); };
 
     // ---- phase 1: sample records -------------------------------------------------------------
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
-        const int q = t.q0 + r;
+        const int q = query_of(r);
         int off[4] = {-1, -1, -1, -1};
         float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < Lq) {
+        if (q >= 0) {
             const int l = k / P;
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
             const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
@@ -252,7 +296,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     // ---- phase 2: gather + weighted sum ------------------------------------------------------
     const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
     const int r = g / SPLIT, part = g % SPLIT;
-    const int q = t.q0 + r;
+    const int q = query_of(r);
     const float *vb = value + ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 *ro = rec_off + r * LPP;
@@ -276,9 +320,11 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
             acc.w += __shfl_xor(acc.w, s, 64);
         }
     }
-    if (part == 0 && q < Lq) {
+    if (part == 0 && q >= 0) {
         const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
         *reinterpret_cast<float4 *>(out + row * kD + 4 * j) = acc;
+    }
+    if (!PATCH) return;
     }
 }
 
@@ -613,7 +659,7 @@ __global__ __launch_bounds__(kWinThreads, 6) void msda_bwd_scatter_d32_win(
                 if (inw[cidx]) rank[cidx] = atomicAdd(&cnt[wrow[cidx]], 1);
                 else   // off = pixel index * rs: keep the pixel index (< 2^25, checked by the launcher) + the query
                     entries[kNE - 1 - atomicAdd(&stats[1], 1)] =
-                        make_float2(cw[cidx], __int_as_float((i << 25) | (off[cidx] / rs)));
+                        make_float2(cw[cidx], __int_as_float((int)(((unsigned)i << 25) | (unsigned)(off[cidx] / rs))));
             }
             __syncthreads();
             // ---- exclusive scan of the kWR counters -> start[]  (thread t owns counters 2t, 2t+1)
@@ -782,13 +828,25 @@ extern "C" int semidetr_msda_forward_f32(void *stream, const float *value, const
     const int64_t grid = (int64_t)N * tiles * M;
     SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
     const size_t lds = (size_t)rpb * (L * P + 1) * 32;
-#define LAUNCH_FWD(SP, UN)                                                                                  \
-    hipLaunchKernelGGL((msda_fwd_d32<SP, UN>), dim3((unsigned)grid), dim3(256), lds, st, value,             \
-                       spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq, P, tiles, out)
+#define LAUNCH_FWD(SP, UN, PT, TILES)                                                                       \
+    hipLaunchKernelGGL((msda_fwd_d32<SP, UN, PT>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), lds, st, \
+                       value, spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq, P, (TILES), out)
+    if ((Lq == S && g_fwd_variant == 0) || g_fwd_variant == 408 || g_fwd_variant == 804 || g_fwd_variant == 216) {
+        SEMIDETR_REQUIRE(Lq == S, SEMIDETR_E_BADARG, "msda_forward: patch tiling needs num_query == spatial_size");
+        // grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges included)
+        const int bound = (S + 31) / 32 * 5 / 4 + 4 * L;
+        SEMIDETR_REQUIRE((int64_t)N * bound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
+        const size_t lds = (size_t)32 * (L * P + 1) * 32;
+        // measured at the 800x1333 encoder shape, bs 4: strips 299 us, 4x8 284, 8x4 281, 2x16 286
+        if (g_fwd_variant == 408) LAUNCH_FWD(1, 4, 408, bound);
+        else if (g_fwd_variant == 216) LAUNCH_FWD(1, 4, 216, bound);
+        else LAUNCH_FWD(1, 4, 804, bound);
+        return semidetr::launch_status("msda_fwd_d32<patch>");
+    }
     const int unroll = g_fwd_variant >= 10 && g_fwd_variant < 100 ? g_fwd_variant / 10 : 4;
-    if (split == 1) { if (unroll == 2) LAUNCH_FWD(1, 2); else if (unroll == 1) LAUNCH_FWD(1, 1); else LAUNCH_FWD(1, 4); }
-    else if (split == 2) LAUNCH_FWD(2, 4);
-    else LAUNCH_FWD(4, 4);
+    if (split == 1) { if (unroll == 2) LAUNCH_FWD(1, 2, 0, tiles); else if (unroll == 1) LAUNCH_FWD(1, 1, 0, tiles); else LAUNCH_FWD(1, 4, 0, tiles); }
+    else if (split == 2) LAUNCH_FWD(2, 4, 0, tiles);
+    else LAUNCH_FWD(4, 4, 0, tiles);
 #undef LAUNCH_FWD
     return semidetr::launch_status("msda_fwd_d32");
 }
