@@ -574,14 +574,15 @@ constexpr int kWinThreads = 512;                        // 8 wavefronts = 16 hal
 constexpr int kPT = 4;                                  // num_point (compile time: one sample per thread)
 constexpr int kNE = kTQ * kPT * 4;                      // corners per (patch, level)
 
-__global__ __launch_bounds__(kWinThreads, 6) void msda_bwd_scatter_d32_win(
+__global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int tiles_bound,
     float *__restrict__ gvalue)
 {
     static_assert(kTQ * kPT == kWinThreads, "one (query, point) sample per thread");
     static_assert(kWR <= 2 * kWinThreads, "scan assigns two counters per thread");
-    __shared__ float2 entries[kNE];              // front: bucketed {weight, window row << 8 | query};
+    __shared__ float2 entries[kNE + 8];          // front: bucketed {weight, window row << 8 | query} (+8: batch
+                                                 //        reads may run past a share's end, results unused);
                                                  // back : misses {weight, query << 25 | pixel index}
     __shared__ float gtile[kTQ * kD];            // grad_out rows of the patch
     __shared__ int cnt[kWR], start[kWR];
@@ -594,7 +595,6 @@ __global__ __launch_bounds__(kWinThreads, 6) void msda_bwd_scatter_d32_win(
     const int m = b % M;
     const int slot = (b / M) % tiles_bound, n = (b / M) / tiles_bound;
     const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
-    float *gvb = gvalue + ((int64_t)n * S * M + m) * kD + c;     // lane = channel
 
     for (int tile = slot;; tile += tiles_bound) {
         // ---- which patch of which level is tile number `tile`? (uniform across the workgroup)
@@ -615,9 +615,9 @@ __global__ __launch_bounds__(kWinThreads, 6) void msda_bwd_scatter_d32_win(
         // patch centre in normalised coordinates (pixel centres are (i + 0.5) / size)
         const float pcy = (ty * kTH + 0.5f * kTH) / (float)Hq, pcx = (tx * kTW + 0.5f * kTW) / (float)Wq;
         __syncthreads();                      // previous patch fully done before its LDS state is reused
-        for (int r = hw; r < kTQ; r += kWinThreads / 32) {      // stage grad_out of the patch
-            const int ry = ty * kTH + r / kTW, rx = tx * kTW + r % kTW;
-            gtile[r * kD + c] =
+        for (int r = hw; r < kTQ; r += kWinThreads / 32) {      // stage grad_out of the patch, channels (c, c+16)
+            const int ry = ty * kTH + r / kTW, rx = tx * kTW + r % kTW;   // interleaved: lane l of a 16-lane stream
+            gtile[r * kD + (c & 15) * 2 + (c >> 4)] =                     // reads both with one ds_read_b64
                 (ry < Hq && rx < Wq) ? gout[(((int64_t)n * Lq + stq + ry * Wq + rx) * M + m) * kD + c] : 0.f;
         }
         for (int l = 0; l < L; ++l) {
@@ -689,46 +689,66 @@ __global__ __launch_bounds__(kWinThreads, 6) void msda_bwd_scatter_d32_win(
                 if (off[cidx] >= 0 && inw[cidx])
                     entries[start[wrow[cidx]] + rank[cidx]] = make_float2(cw[cidx], __int_as_float((wrow[cidx] << 8) | i));
             __syncthreads();
-            // ---- owner computes: every half-wave walks an equal share of the row-sorted entries
+            // ---- owner computes: 32 streams of 16 lanes (lane l = channels l and l+16) each walk an equal share
+            //      of the row-sorted entries, keep the running row sum in two registers and flush a finished row
+            //      with two half-line atomics (64 contiguous bytes each = the same 2 atomic units as one full row)
             {
+                constexpr int kStreams = kWinThreads / 16;
+                const int sid = tid >> 4, l16 = tid & 15;
+                const float2 *gt2 = reinterpret_cast<const float2 *>(gtile);
+                float *gvs = gvalue + ((int64_t)n * S * M + m) * kD + l16;
                 const int total = stats[3];
-                const int lo = (int)((int64_t)total * hw / (kWinThreads / 32));
-                const int hi = (int)((int64_t)total * (hw + 1) / (kWinThreads / 32));
+                const int lo = (int)((int64_t)total * sid / kStreams);
+                const int hi = (int)((int64_t)total * (sid + 1) / kStreams);
                 int cur = -1;
-                float accv = 0.f;
-                for (int e = lo; e < hi; e += 8) {
-                    // software pipeline: 8 independent entry reads, then 8 independent grad_out reads, then the
-                    // (short) dependent accumulate / row-change chain
-                    float2 en[8];
-                    float gq[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) en[u] = entries[min(e + u, hi - 1)];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) gq[u] = gtile[(__float_as_int(en[u].y) & 255) * kD + c];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (e + u < hi) {
-                            const int rowi = __float_as_int(en[u].y) >> 8;
-                            if (rowi != cur) {
-                                if (cur >= 0)
-                                    fp_atomic_add(gvb + (int64_t)(st + (y0 + cur / kWW) * W + x0 + cur % kWW) * rs, accv);
-                                cur = rowi;
-                                accv = 0.f;
-                            }
-                            accv += en[u].x * gq[u];
-                        }
+                float2 accv = make_float2(0.f, 0.f);
+                auto flush = [&](int rowi) {
+                    float *pr = gvs + (int64_t)(st + (y0 + rowi / kWW) * W + x0 + rowi % kWW) * rs;
+                    fp_atomic_add(pr, accv.x);
+                    fp_atomic_add(pr + 16, accv.y);
+                };
+                // software pipeline: 8 independent entry reads, then 8 independent grad_out reads, then the (short)
+                // dependent accumulate / row-change chain.  Full batches run without bounds checks.
+                auto step = [&](const float2 &en, const float2 &gq) {
+                    const int rowi = __float_as_int(en.y) >> 8;
+                    if (rowi != cur) {
+                        if (cur >= 0) flush(cur);
+                        cur = rowi;
+                        accv = make_float2(0.f, 0.f);
                     }
+                    accv.x += en.x * gq.x;
+                    accv.y += en.x * gq.y;
+                };
+                int e = lo;
+                for (; e + 8 <= hi; e += 8) {
+                    float2 en[8], gq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) en[u] = entries[e + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 255) * 16 + l16];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) step(en[u], gq[u]);
                 }
-                if (cur >= 0) fp_atomic_add(gvb + (int64_t)(st + (y0 + cur / kWW) * W + x0 + cur % kWW) * rs, accv);
-            }
-            // ---- misses: one full-line atomic per (sample, corner), as the plain kernel does
-            {
+                if (e < hi) {       // tail of < 8 entries (reads stay inside the padded array)
+                    float2 en[8], gq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) en[u] = entries[e + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 255) * 16 + l16];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (e + u < hi) step(en[u], gq[u]);
+                }
+                if (cur >= 0) flush(cur);
+                // ---- misses: one row update per (sample, corner), as the plain kernel does
                 const int nmiss = stats[1];
-                for (int mi = hw; mi < nmiss; mi += kWinThreads / 32) {
+                for (int mi = sid; mi < nmiss; mi += kStreams) {
                     const float2 en = entries[kNE - 1 - mi];
                     const int pk = __float_as_int(en.y);
-                    const int64_t oc = (int64_t)(pk & 0x1ffffff) * rs;
-                    fp_atomic_add(gvb + oc, en.x * gtile[((unsigned)pk >> 25) * kD + c]);
+                    const float2 g2 = gt2[((unsigned)pk >> 25) * 16 + l16];
+                    float *pr = gvs + (int64_t)(pk & 0x1ffffff) * rs;
+                    fp_atomic_add(pr, en.x * g2.x);
+                    fp_atomic_add(pr + 16, en.x * g2.y);
                 }
             }
         }
