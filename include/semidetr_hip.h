@@ -72,6 +72,36 @@ int semidetr_msda_backward_f64(void *stream, const double *grad_out, const doubl
                                int num_query, int num_point, double *grad_value,
                                double *grad_sampling_loc, double *grad_attn_weight);
 
+/* ---------------------------------------------------------------------------------------------
+ * MSDA with the MSDeformAttn prologue / epilogue fused in (fp32, channels == 32).
+ *
+ * Replaces  MSDeformAttn.forward lines between the Linear layers
+ *           detr_od/models/utils/ops/modules/ms_deform_attn.py:99-111  (softmax over L*P, sampling_locations =
+ *           reference_points + offsets / (W_l, H_l)   [ref_dim 2]   or
+ *           reference_points[:2] + offsets / P * reference_points[2:] * 0.5   [ref_dim 4])
+ *           together with MSDeformAttnFunction.apply (:121-123) and their autograd backward.
+ * The kernels read the RAW outputs of the two Linear layers, so the (N,Lq,M,L,P,2) locations tensor, the
+ * softmaxed weights and their gradients never exist in HBM.
+ *   reference_points  (batch, num_query, num_levels, ref_dim)       ref_dim 2 or 4
+ *   sampling_offsets  (batch, num_query, num_heads, num_levels, num_point, 2)   raw Linear output
+ *   attn_logits       (batch, num_query, num_heads, num_levels * num_point)     raw Linear output (pre-softmax)
+ *   grad_sampling_offsets / grad_attn_logits: same shapes, every element written.
+ * (The gradient w.r.t. reference_points, when a caller needs it, follows from grad_sampling_offsets on the
+ *  host side; the reference detaches reference points between decoder layers, transformer.py:1033.)
+ * ------------------------------------------------------------------------------------------- */
+int semidetr_msda_fused_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                    const int64_t *level_start, const float *reference_points, int ref_dim,
+                                    const float *sampling_offsets, const float *attn_logits, int batch,
+                                    int spatial_size, int num_heads, int channels, int num_levels,
+                                    int num_query, int num_point, float *out);
+int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const float *value,
+                                     const int64_t *spatial_shapes, const int64_t *level_start,
+                                     const float *reference_points, int ref_dim,
+                                     const float *sampling_offsets, const float *attn_logits, int batch,
+                                     int spatial_size, int num_heads, int channels, int num_levels,
+                                     int num_query, int num_point, float *grad_value,
+                                     float *grad_sampling_offsets, float *grad_attn_logits);
+
 /* Tuning knob for benchmarking the f32 / channels==32 fast path: variant 0 = automatic choice,
  * >0 forces a kernel variant; process-wide, not thread-safe, tests leave it at 0. */
 void semidetr_msda_set_variant(int fwd_variant, int bwd_variant);

@@ -103,3 +103,68 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 _p(grad_value), _p(grad_loc), _p(grad_attn))
     _lib.check(rc, "ms_deform_attn_backward")
     return [grad_value, grad_loc, grad_attn]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fused prologue / epilogue (not part of the reference's pybind surface)
+# ---------------------------------------------------------------------------------------------------
+def fused_supported(value, reference_points, sampling_offsets, attn_logits):
+    """The fused kernels cover the DINO configuration: fp32, 32 channels per head, reference dim 2 or 4."""
+    return (value.is_cuda and value.dtype == torch.float32 and value.dim() == 4 and value.shape[3] == 32
+            and reference_points.shape[-1] in (2, 4) and sampling_offsets.dtype == torch.float32
+            and attn_logits.dtype == torch.float32 and reference_points.dtype == torch.float32)
+
+
+def _fused_dims(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits):
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("reference_points", reference_points), ("sampling_offsets", sampling_offsets),
+                   ("attention logits", attn_logits)])
+    _assert(spatial_shapes.dtype == torch.int64 and level_start_index.dtype == torch.int64,
+            "expected scalar type Long for spatial_shapes / level_start_index")
+    _assert(sampling_offsets.dim() == 6 and attn_logits.dim() == 4 and reference_points.dim() == 4,
+            "ms_deform_attn_fused: expected sampling_offsets (N,Lq,M,L,P,2), logits (N,Lq,M,L*P), reference (N,Lq,L,2|4)")
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_offsets.shape
+    _assert(tuple(attn_logits.shape) == (N, Lq, M, L * P) and tuple(reference_points.shape[:3]) == (N, Lq, L)
+            and spatial_shapes.shape[0] == L, "ms_deform_attn_fused: inconsistent tensor shapes")
+    if reference_points.shape[-1] not in (2, 4):
+        raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead."
+                         .format(reference_points.shape[-1]))
+    return N, S, M, D, L, Lq, P
+
+
+def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                                 attn_logits):
+    """MSDeformAttn.forward between the Linear layers (ms_deform_attn.py:99-123) in one launch."""
+    N, S, M, D, L, Lq, P = _fused_dims(value, spatial_shapes, level_start_index, reference_points,
+                                       sampling_offsets, attn_logits)
+    with torch.cuda.device(value.device):
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        if out.numel() == 0 or value.numel() == 0:
+            return out.zero_()
+        rc = _lib.lib().semidetr_msda_fused_forward_f32(
+            _lib.current_stream_ptr(), _p(value), _p(spatial_shapes), _p(level_start_index), _p(reference_points),
+            reference_points.shape[-1], _p(sampling_offsets), _p(attn_logits), N, S, M, D, L, Lq, P, _p(out))
+    _lib.check(rc, "ms_deform_attn_fused_forward")
+    return out
+
+
+def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                                  attn_logits, grad_output):
+    """-> [grad_value, grad_sampling_offsets, grad_attn_logits]."""
+    N, S, M, D, L, Lq, P = _fused_dims(value, spatial_shapes, level_start_index, reference_points,
+                                       sampling_offsets, attn_logits)
+    _assert(grad_output.is_contiguous() and grad_output.numel() == N * Lq * M * D and grad_output.dtype == value.dtype,
+            "ms_deform_attn_fused_backward: grad_output must be a contiguous (N, Lq, M*D) tensor of value's dtype")
+    with torch.cuda.device(value.device):
+        grad_value = torch.empty_like(value)
+        grad_off = torch.empty_like(sampling_offsets)
+        grad_logit = torch.empty_like(attn_logits)
+        if value.numel() == 0 or grad_off.numel() == 0:
+            return [grad_value.zero_(), grad_off.zero_(), grad_logit.zero_()]
+        rc = _lib.lib().semidetr_msda_fused_backward_f32(
+            _lib.current_stream_ptr(), _p(grad_output), _p(value), _p(spatial_shapes), _p(level_start_index),
+            _p(reference_points), reference_points.shape[-1], _p(sampling_offsets), _p(attn_logits), N, S, M, D, L,
+            Lq, P, _p(grad_value), _p(grad_off), _p(grad_logit))
+    _lib.check(rc, "ms_deform_attn_fused_backward")
+    return [grad_value, grad_off, grad_logit]

@@ -15,13 +15,13 @@ from . import MultiScaleDeformableAttention as _msda_native
 # (detr_od/models/utils/ops/functions/ms_deform_attn_func.py:18); make that import resolve to ours.
 _sys.modules.setdefault("MultiScaleDeformableAttention", _msda_native)
 
-from .ops.functions import MSDeformAttnFunction  # noqa: E402,F401
+from .ops.functions import MSDeformAttnFunction, MSDeformAttnFusedFunction  # noqa: E402,F401
 from .ops.modules import MSDeformAttn  # noqa: E402,F401
 from .matcher import (AssignResult, BBoxL1Cost, FocalLossCost, HungarianAssigner, IoUCost,  # noqa: E402,F401
                       linear_sum_assignment)
 from .mean_teacher import MeanTeacher, ema_momentum, ema_update_, ema_update_flat_  # noqa: E402,F401
 from .pseudo_label import filter_pseudo_labels  # noqa: E402,F401
 
-__all__ = ["MSDeformAttnFunction", "MSDeformAttn", "HungarianAssigner", "FocalLossCost", "BBoxL1Cost",
+__all__ = ["MSDeformAttnFunction", "MSDeformAttnFusedFunction", "MSDeformAttn", "HungarianAssigner", "FocalLossCost", "BBoxL1Cost",
            "IoUCost", "AssignResult", "linear_sum_assignment", "MeanTeacher", "ema_momentum", "ema_update_",
            "ema_update_flat_", "filter_pseudo_labels"]

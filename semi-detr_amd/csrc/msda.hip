@@ -170,6 +170,79 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Where a fast-path kernel gets the (x, y, attention) of a sample from, and where the backward puts the two
+// small gradients.  LocAttnIO is the reference op contract.  RawIO is the fused prologue/epilogue of
+// MSDeformAttn.forward (detr_od/models/utils/ops/modules/ms_deform_attn.py:94-111): the kernels consume the
+// reference points, the RAW sampling offsets and the RAW attention logits (the outputs of the two Linear
+// layers) and do the softmax over L*P and the location arithmetic themselves, so the (N,Lq,M,L,P[,2])
+// intermediates (and their backward) never touch HBM.
+// ---------------------------------------------------------------------------------------------
+struct LocAttnIO {
+    const float *loc, *attn;
+    float *gloc, *gattn;
+    static constexpr bool kSoftmax = false;      // attn already holds probabilities
+    __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                            float &x, float &y) const
+    {
+        (void)nq; (void)l; (void)P; (void)H; (void)W;
+        const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
+        x = xy.x;
+        y = xy.y;
+    }
+    __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return attn[row * LP + k]; }
+    // res = {d/d attn, d/d loc.x, d/d loc.y, attn} of sample k; row_res = the LP results of the same (n,q,m) row
+    __device__ __forceinline__ void store(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                          const float4 res, const float4 *row_res) const
+    {
+        (void)nq; (void)l; (void)P; (void)H; (void)W; (void)row_res;
+        gattn[row * LP + k] = res.x;
+        *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
+    }
+};
+
+struct RawIO {
+    const float *ref, *off, *logit;      // (N,Lq,L,ref_dim), (N,Lq,M,L,P,2), (N,Lq,M,L*P)
+    float *goff, *glogit;
+    int ref_dim, M, L;
+    static constexpr bool kSoftmax = true;       // load_w returns a raw logit; the kernel normalises the row
+    __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                            float &x, float &y) const
+    {
+        const float *rp = ref + (nq * L + l) * ref_dim;
+        const float2 o = *reinterpret_cast<const float2 *>(off + (row * LP + k) * 2);
+        if (ref_dim == 2) {          // ms_deform_attn.py:102-105
+            x = rp[0] + o.x / (float)W;
+            y = rp[1] + o.y / (float)H;
+        } else {                     // ms_deform_attn.py:106-108
+            x = rp[0] + o.x / (float)P * rp[2] * 0.5f;
+            y = rp[1] + o.y / (float)P * rp[3] * 0.5f;
+        }
+    }
+    __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return logit[row * LP + k]; }
+    // called by the LP consecutive threads that own the row's samples (see row_softmax)
+    __device__ __forceinline__ void store(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                          const float4 res, const float4 *row_res) const
+    {
+        float dot = res.w * res.x;               // softmax backward: a_k * (g_k - sum_j a_j g_j)
+        if ((LP & (LP - 1)) == 0 && LP <= 64) {
+            for (int d = 1; d < LP; d <<= 1) dot += __shfl_xor(dot, d, 64);
+        } else {                                 // generic LP: every thread re-reads the row (rare)
+            dot = 0.f;
+            for (int j = 0; j < LP; ++j) dot += row_res[j].w * row_res[j].x;
+        }
+        glogit[row * LP + k] = res.w * (res.x - dot);
+        float2 g;
+        if (ref_dim == 2) {
+            g = make_float2(res.y / (float)W, res.z / (float)H);
+        } else {
+            const float *rp = ref + (nq * L + l) * ref_dim;
+            g = make_float2(res.y * 0.5f * rp[2] / (float)P, res.z * 0.5f * rp[3] / (float)P);
+        }
+        *reinterpret_cast<float2 *>(goff + (row * LP + k) * 2) = g;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // fast path: fp32, D == 32.  8 lanes x float4 per 128-byte value row.
 // ---------------------------------------------------------------------------------------------
 constexpr int kD = 32;
@@ -192,6 +265,29 @@ __device__ __forceinline__ float group8_sum(float x)
 __device__ __forceinline__ float4 ld4(const float *p, int off)
 {
     return off >= 0 ? *reinterpret_cast<const float4 *>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Softmax over the L*P logits of one (n, q, m) row (ms_deform_attn.py:101), evaluated cooperatively by the LP
+// consecutive threads that own the row's samples: one expf per sample, max / sum by xor-shuffles when LP is a
+// power of two <= 64 (the DINO case LP = 16 is one DPP row); any other LP falls back to a per-thread loop.
+template <typename IO>
+__device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, int k, float raw)
+{
+    if (!IO::kSoftmax) return raw;
+    if ((LP & (LP - 1)) == 0 && LP <= 64) {
+        float mx = raw;
+        for (int d = 1; d < LP; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        const float e = expf(raw - mx);
+        float sum = e;
+        for (int d = 1; d < LP; d <<= 1) sum += __shfl_xor(sum, d, 64);
+        return e / sum;
+    }
+    float mx = raw;
+    for (int j = 0; j < LP; ++j) mx = fmaxf(mx, io.load_w(row, LP, j));
+    float sum = 0.f;
+    for (int j = 0; j < LP; ++j) sum += expf(io.load_w(row, LP, j) - mx);
+    (void)k;
+    return expf(raw - mx) / sum;
 }
 
 // Workgroup -> (n, query tile, m): m fastest so that blockIdx % 8 == m % 8 when M % 8 == 0 (L2 affinity,
@@ -243,11 +339,10 @@ __device__ __forceinline__ int patch_query(const Patch &p, int r)      // r-th q
 }
 
 // SPLIT = number of 8-lane groups that share one (q) row; each takes samples k = part, part+SPLIT, ...
-template <int SPLIT, int UNROLL, int PATCH = 0>
+template <int SPLIT, int UNROLL, int PATCH = 0, typename IO = LocAttnIO>
 __global__ __launch_bounds__(256) void msda_fwd_d32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
-    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int Lq, int P,
-    int tiles_per_image, float *__restrict__ out)
+    const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ out)
 {
     constexpr int RPB = 32 / SPLIT;   // query rows per workgroup
     extern __shared__ float4 smem[];
@@ -279,11 +374,11 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
         if (q >= 0) {
             const int l = k / P;
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
-            const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
-            const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
-            float lw, lh;
-            if (sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh)) {
-                const float a = attn[row * LP + k];
+            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
+            float x, y, lw, lh;
+            io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
+            const float a = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 w = make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw));
             }
@@ -346,12 +441,11 @@ __device__ __forceinline__ float half32_sum(float x)
 // atomics cost ~one unit per 64-byte half-line touched (~20.8 G units/s chip-wide), so full-row updates move
 // 4x more gradient per unit than the 8-lane x float4 layout the forward uses.
 // RPB = query rows per 256-thread workgroup (8 half-waves, each walks RPB/8 rows).
-template <int RPB>
+template <int RPB, typename IO = LocAttnIO>
 __global__ __launch_bounds__(256) void msda_bwd_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn,
-    int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ gvalue,
-    float *__restrict__ gloc, float *__restrict__ gattn)
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image,
+    float *__restrict__ gvalue)
 {
     extern __shared__ float4 smem[];
     const int LP = L * P, LPP = LP + 1;
@@ -373,13 +467,14 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
         float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
         if (q < Lq) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
-            const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
-            const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
-            float lw, lh;
-            if (sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh)) {
+            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
+            float x, y, lw, lh;
+            io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
+            // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
+            pr.z = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
                 pr.x = lw;
                 pr.y = lh;
-                pr.z = attn[row * LP + k];
             }
         }
         rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
@@ -421,7 +516,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
             pa = half32_sum(pa);
             px = half32_sum(px);
             py = half32_sum(py);
-            if (c == 16) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, 0.f);
+            if (c == 16) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, a);
         }
     }
     __syncthreads();
@@ -431,10 +526,9 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
         const int rr = s / LP, k = s - rr * LP;
         const int qq = t.q0 + rr;
         if (qq >= Lq) continue;
-        const int64_t row = ((int64_t)t.n * Lq + qq) * M + t.m;
-        const float4 res = rec_p[rr * LPP + k];
-        gattn[row * LP + k] = res.x;
-        *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
+        const int64_t nq = (int64_t)t.n * Lq + qq, row = nq * M + t.m;
+        const int l = k / P;
+        io.store(row, nq, LP, k, l, P, (int)lev_h[l], (int)lev_w[l], rec_p[rr * LPP + k], rec_p + rr * LPP);
     }
 }
 
@@ -443,11 +537,10 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
 // sample, NO grad_value scatter.  Same tiling / LDS records / 8-lane x float4 loads as msda_fwd_d32<1>; the
 // three channel sums per sample are 3 DPP steps inside the 8-lane group.  Streams like the forward (no
 // atomics, no per-level barriers), used together with the owner-computes scatter kernel below.
+template <typename IO = LocAttnIO>
 __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ starts, const float *__restrict__ loc, const float *__restrict__ attn,
-    int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ gloc,
-    float *__restrict__ gattn)
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
 {
     constexpr int RPB = 32;
     extern __shared__ float4 smem[];
@@ -470,13 +563,14 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
         float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
         if (q < Lq) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
-            const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
-            const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
-            float lw, lh;
-            if (sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh)) {
+            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
+            float x, y, lw, lh;
+            io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
+            // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
+            pr.z = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
                 pr.x = lw;
                 pr.y = lh;
-                pr.z = attn[row * LP + k];
             }
         }
         rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
@@ -532,7 +626,7 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
             pa = group8_sum(pa);
             px = group8_sum(px);
             py = group8_sum(py);
-            if (j == 0) rp[k0 + u] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, 0.f);
+            if (j == 0) rp[k0 + u] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, a);
         }
     }
     __syncthreads();
@@ -540,10 +634,9 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
         const int rr = s / LP, k = s - rr * LP;
         const int qq = t.q0 + rr;
         if (qq >= Lq) continue;
-        const int64_t row = ((int64_t)t.n * Lq + qq) * M + t.m;
-        const float4 res = rec_p[rr * LPP + k];
-        gattn[row * LP + k] = res.x;
-        *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
+        const int64_t nq = (int64_t)t.n * Lq + qq, row = nq * M + t.m;
+        const int l = k / P;
+        io.store(row, nq, LP, k, l, P, (int)lev_h[l], (int)lev_w[l], rec_p[rr * LPP + k], rec_p + rr * LPP);
     }
 }
 
@@ -574,10 +667,10 @@ constexpr int kWinThreads = 512;                        // 8 wavefronts = 16 hal
 constexpr int kPT = 4;                                  // num_point (compile time: one sample per thread)
 constexpr int kNE = kTQ * kPT * 4;                      // corners per (patch, level)
 
+template <typename IO = LocAttnIO>
 __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
-    const float *__restrict__ loc, const float *__restrict__ attn, int S, int M, int L, int tiles_bound,
-    float *__restrict__ gvalue)
+    const IO io, int S, int M, int L, int tiles_bound, float *__restrict__ gvalue)
 {
     static_assert(kTQ * kPT == kWinThreads, "one (query, point) sample per thread");
     static_assert(kWR <= 2 * kWinThreads, "scan assigns two counters per thread");
@@ -614,6 +707,23 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
         const int64_t srow = q >= 0 ? ((int64_t)n * Lq + q) * M + m : 0;
         // patch centre in normalised coordinates (pixel centres are (i + 0.5) / size)
         const float pcy = (ty * kTH + 0.5f * kTH) / (float)Hq, pcx = (tx * kTW + 0.5f * kTW) / (float)Wq;
+        // fused prologue: softmax statistics of this thread's (query, head) row, once per patch.  The row's L*P
+        // logits belong to the P threads of the query (a quad for P = 4), L each: quad reductions.
+        float sm_max = 0.f, sm_inv = 1.f;
+        if (IO::kSoftmax) {
+            float mx = -__builtin_huge_valf();
+            if (q >= 0)
+                for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow, LP, l * P + p));
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            float sum = 0.f;
+            if (q >= 0)
+                for (int l = 0; l < L; ++l) sum += expf(io.load_w(srow, LP, l * P + p) - mx);
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sm_max = mx;
+            sm_inv = 1.f / sum;
+        }
         __syncthreads();                      // previous patch fully done before its LDS state is reused
         for (int r = hw; r < kTQ; r += kWinThreads / 32) {      // stage grad_out of the patch, channels (c, c+16)
             const int ry = ty * kTH + r / kTW, rx = tx * kTW + r % kTW;   // interleaved: lane l of a 16-lane stream
@@ -634,12 +744,14 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
             int h0 = 0, w0 = 0;
             if (q >= 0) {
                 const int k = l * P + p;
-                const float2 xy = *reinterpret_cast<const float2 *>(loc + (srow * LP + k) * 2);
-                if (sample_setup(xy.x, xy.y, H, W, st, rs, off, lw, lh)) {
-                    a = attn[srow * LP + k];
+                float x, y;
+                io.load_xy(srow, (int64_t)n * Lq + q, LP, k, l, P, H, W, x, y);
+                if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+                    a = io.load_w(srow, LP, k);
+                    if (IO::kSoftmax) a = expf(a - sm_max) * sm_inv;
                     // the top-left corner (h0, w0) exactly as sample_setup derived it
-                    h0 = (int)floorf(sub_rn(mul_rn(xy.y, (float)H), 0.5f));
-                    w0 = (int)floorf(sub_rn(mul_rn(xy.x, (float)W), 0.5f));
+                    h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
+                    w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
                 }
             }
             __syncthreads();                  // counters zeroed, previous level's walk finished
@@ -818,6 +930,84 @@ int pick_split(int forced, int N, int Lq, int M)
     return 4;
 }
 
+// ---- fast-path launchers, shared by the reference contract (LocAttnIO) and the fused prologue (RawIO) ----
+template <typename IO>
+int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spatial_shapes,
+                        const int64_t *level_start, const IO &io, int N, int S, int M, int L, int Lq, int P,
+                        float *out)
+{
+    const int split = pick_split(g_fwd_variant % 10, N, Lq, M);
+    const int rpb = 32 / split;
+    const int tiles = (Lq + rpb - 1) / rpb;
+    const int64_t grid = (int64_t)N * tiles * M;
+    SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
+    const size_t lds = (size_t)rpb * (L * P + 1) * 32;
+#define LAUNCH_FWD(SP, UN, PT, TILES)                                                                       \
+    hipLaunchKernelGGL((msda_fwd_d32<SP, UN, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
+                       lds, st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
+    if ((Lq == S && g_fwd_variant == 0) || g_fwd_variant == 408 || g_fwd_variant == 804 || g_fwd_variant == 216) {
+        SEMIDETR_REQUIRE(Lq == S, SEMIDETR_E_BADARG, "msda_forward: patch tiling needs num_query == spatial_size");
+        // grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges included)
+        const int bound = (S + 31) / 32 * 5 / 4 + 4 * L;
+        SEMIDETR_REQUIRE((int64_t)N * bound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
+        const size_t lds = (size_t)32 * (L * P + 1) * 32;
+        // measured at the 800x1333 encoder shape, bs 4: strips 299 us, 4x8 284, 8x4 281, 2x16 286
+        if (g_fwd_variant == 408) LAUNCH_FWD(1, 4, 408, bound);
+        else if (g_fwd_variant == 216) LAUNCH_FWD(1, 4, 216, bound);
+        else LAUNCH_FWD(1, 4, 804, bound);
+        return semidetr::launch_status("msda_fwd_d32<patch>");
+    }
+    const int unroll = g_fwd_variant >= 10 && g_fwd_variant < 100 ? g_fwd_variant / 10 : 4;
+    if (split == 1) { if (unroll == 2) LAUNCH_FWD(1, 2, 0, tiles); else if (unroll == 1) LAUNCH_FWD(1, 1, 0, tiles); else LAUNCH_FWD(1, 4, 0, tiles); }
+    else if (split == 2) LAUNCH_FWD(2, 4, 0, tiles);
+    else LAUNCH_FWD(4, 4, 0, tiles);
+#undef LAUNCH_FWD
+    return semidetr::launch_status("msda_fwd_d32");
+}
+
+template <typename IO>
+int launch_fast_backward(hipStream_t st, const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                         const int64_t *level_start, const IO &io, int N, int S, int M, int L, int Lq, int P,
+                         float *grad_value)
+{
+    hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * kD, st);
+    if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+    if ((Lq == S && P == kPT && S < (1 << 25) && g_bwd_variant == 0) || g_bwd_variant == 64) {
+        SEMIDETR_REQUIRE(Lq == S && P == kPT && S < (1 << 25), SEMIDETR_E_BADARG,
+                         "msda_backward: the windowed kernel needs num_query == spatial_size < 2^25 and num_point == 4");
+        // patches are enumerated on the device (the level table lives in device memory); a workgroup takes
+        // patches slot, slot + tiles_bound, ... so any bound >= 1 is correct; this one covers the usual
+        // pyramids (sum of ceil(H/8)*ceil(W/16) <= S/128 * 1.25 + 4 per level) in a single round.
+        const int tiles_bound = (S + kTQ - 1) / kTQ * 5 / 4 + 4 * L;
+        const int64_t grid = (int64_t)N * tiles_bound * M;
+        SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+        {   // gather half: the two small gradients, streams like the forward
+            const int gt = (Lq + 31) / 32;
+            const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
+            hipLaunchKernelGGL(msda_bwd_gather_d32<IO>, dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
+                               grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
+            if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
+        }
+        hipLaunchKernelGGL(msda_bwd_scatter_d32_win<IO>, dim3((unsigned)grid), dim3(kWinThreads), 0, st, grad_out,
+                           spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
+        return semidetr::launch_status("msda_bwd_scatter_d32_win");
+    }
+    // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles
+    int rpb = (int64_t)N * M * ((Lq + 31) / 32) >= 1024 ? 32 : 8;
+    if (g_bwd_variant == 8 || g_bwd_variant == 32) rpb = g_bwd_variant;
+    const int tiles = (Lq + rpb - 1) / rpb;
+    const int64_t grid = (int64_t)N * tiles * M;
+    SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+    const size_t lds = (size_t)rpb * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
+#define LAUNCH_BWD(R)                                                                                       \
+    hipLaunchKernelGGL((msda_bwd_d32<R, IO>), dim3((unsigned)grid), dim3(256), lds, st, grad_out, value,    \
+                       spatial_shapes, level_start, io, S, M, L, Lq, P, tiles, grad_value)
+    if (rpb == 32) LAUNCH_BWD(32);
+    else LAUNCH_BWD(8);
+#undef LAUNCH_BWD
+    return semidetr::launch_status("msda_bwd_d32");
+}
+
 }  // namespace
 
 extern "C" void semidetr_msda_set_variant(int fwd_variant, int bwd_variant)
@@ -841,44 +1031,9 @@ extern "C" int semidetr_msda_forward_f32(void *stream, const float *value, const
                               Lq, P, 4))
         return rc;
     SEMIDETR_REQUIRE(out, SEMIDETR_E_BADARG, "msda_forward: null output");
-    hipStream_t st = semidetr::as_stream(stream);
-    const int split = pick_split(g_fwd_variant % 10, N, Lq, M);
-    const int rpb = 32 / split;
-    const int tiles = (Lq + rpb - 1) / rpb;
-    const int64_t grid = (int64_t)N * tiles * M;
-    SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
-    const size_t lds = (size_t)rpb * (L * P + 1) * 32;
-#define LAUNCH_FWD(SP, UN, PT, TILES)                                                                       \
-    hipLaunchKernelGGL((msda_fwd_d32<SP, UN, PT>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), lds, st, \
-                       value, spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq, P, (TILES), out)
-    if ((Lq == S && g_fwd_variant == 0) || g_fwd_variant == 408 || g_fwd_variant == 804 || g_fwd_variant == 216) {
-        SEMIDETR_REQUIRE(Lq == S, SEMIDETR_E_BADARG, "msda_forward: patch tiling needs num_query == spatial_size");
-        // grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges included)
-        const int bound = (S + 31) / 32 * 5 / 4 + 4 * L;
-        SEMIDETR_REQUIRE((int64_t)N * bound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
-        const size_t lds = (size_t)32 * (L * P + 1) * 32;
-        // measured at the 800x1333 encoder shape, bs 4: strips 299 us, 4x8 284, 8x4 281, 2x16 286
-        if (g_fwd_variant == 408) LAUNCH_FWD(1, 4, 408, bound);
-        else if (g_fwd_variant == 216) LAUNCH_FWD(1, 4, 216, bound);
-        else LAUNCH_FWD(1, 4, 804, bound);
-        return semidetr::launch_status("msda_fwd_d32<patch>");
-    }
-    const int unroll = g_fwd_variant >= 10 && g_fwd_variant < 100 ? g_fwd_variant / 10 : 4;
-    if (split == 1) { if (unroll == 2) LAUNCH_FWD(1, 2, 0, tiles); else if (unroll == 1) LAUNCH_FWD(1, 1, 0, tiles); else LAUNCH_FWD(1, 4, 0, tiles); }
-    else if (split == 2) LAUNCH_FWD(2, 4, 0, tiles);
-    else LAUNCH_FWD(4, 4, 0, tiles);
-#undef LAUNCH_FWD
-    return semidetr::launch_status("msda_fwd_d32");
-}
-
-extern "C" int semidetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,
-                                         const int64_t *level_start, const double *sampling_loc,
-                                         const double *attn_weight, int batch, int spatial_size,
-                                         int num_heads, int channels, int num_levels, int num_query,
-                                         int num_point, double *out)
-{
-    return forward_impl<double>(stream, value, spatial_shapes, level_start, sampling_loc, attn_weight, batch,
-                                spatial_size, num_heads, channels, num_levels, num_query, num_point, out);
+    const LocAttnIO io = {sampling_loc, attn_weight, nullptr, nullptr};
+    return launch_fast_forward(semidetr::as_stream(stream), value, spatial_shapes, level_start, io, N, S, M, L, Lq,
+                               P, out);
 }
 
 extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, const float *value,
@@ -900,45 +1055,72 @@ extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, c
         return rc;
     SEMIDETR_REQUIRE(grad_out && grad_value && grad_sampling_loc && grad_attn_weight, SEMIDETR_E_BADARG,
                      "msda_backward: null pointer argument");
-    hipStream_t st = semidetr::as_stream(stream);
-    hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * D, st);
-    if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    if ((Lq == S && P == kPT && S < (1 << 25) && g_bwd_variant == 0) || g_bwd_variant == 64) {
-        SEMIDETR_REQUIRE(Lq == S && P == kPT && S < (1 << 25), SEMIDETR_E_BADARG,
-                         "msda_backward: the windowed kernel needs num_query == spatial_size < 2^25 and num_point == 4");
-        // patches are enumerated on the device (the level table lives in device memory); a workgroup takes
-        // patches slot, slot + tiles_bound, ... so any bound >= 1 is correct; this one covers the usual
-        // pyramids (sum of ceil(H/8)*ceil(W/16) <= S/128 * 1.25 + 4 per level) in a single round.
-        const int tiles_bound = (S + kTQ - 1) / kTQ * 5 / 4 + 4 * L;
-        const int64_t grid = (int64_t)N * tiles_bound * M;
-        SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
-        {   // gather half: grad_attn_weight / grad_sampling_loc, streams like the forward
-            const int gt = (Lq + 31) / 32;
-            const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
-            hipLaunchKernelGGL(msda_bwd_gather_d32, dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
-                               grad_out, value, spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq,
-                               P, gt, grad_sampling_loc, grad_attn_weight);
-            if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
-        }
-        hipLaunchKernelGGL(msda_bwd_scatter_d32_win, dim3((unsigned)grid), dim3(kWinThreads), 0, st, grad_out,
-                           spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, tiles_bound, grad_value);
-        return semidetr::launch_status("msda_bwd_scatter_d32_win");
-    }
-    // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles
-    int rpb = (int64_t)N * M * ((Lq + 31) / 32) >= 1024 ? 32 : 8;
-    if (g_bwd_variant == 8 || g_bwd_variant == 32) rpb = g_bwd_variant;
-    const int tiles = (Lq + rpb - 1) / rpb;
-    const int64_t grid = (int64_t)N * tiles * M;
-    SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
-    const size_t lds = (size_t)rpb * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
-#define LAUNCH_BWD(R)                                                                                       \
-    hipLaunchKernelGGL(msda_bwd_d32<R>, dim3((unsigned)grid), dim3(256), lds, st, grad_out, value,          \
-                       spatial_shapes, level_start, sampling_loc, attn_weight, S, M, L, Lq, P, tiles,       \
-                       grad_value, grad_sampling_loc, grad_attn_weight)
-    if (rpb == 32) LAUNCH_BWD(32);
-    else LAUNCH_BWD(8);
-#undef LAUNCH_BWD
-    return semidetr::launch_status("msda_bwd_d32");
+    const LocAttnIO io = {sampling_loc, attn_weight, grad_sampling_loc, grad_attn_weight};
+    return launch_fast_backward(semidetr::as_stream(stream), grad_out, value, spatial_shapes, level_start, io, N, S,
+                                M, L, Lq, P, grad_value);
+}
+
+// ---- fused MSDeformAttn prologue / epilogue (fp32, channels == 32) --------------------------------------
+static int check_fused(const void *value, const void *shapes, const void *starts, const void *ref, int ref_dim,
+                       const void *off, const void *logit, int N, int S, int M, int D, int L, int Lq, int P)
+{
+    if (int rc = check_common(value, shapes, starts, off, logit, N, S, M, D, L, Lq, P, 4)) return rc;
+    SEMIDETR_REQUIRE(ref, SEMIDETR_E_BADARG, "msda_fused: null reference_points");
+    SEMIDETR_REQUIRE(ref_dim == 2 || ref_dim == 4, SEMIDETR_E_BADARG,
+                     "Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
+    SEMIDETR_REQUIRE(D == kD && L <= kMaxLevels && (int64_t)L * P <= 256, SEMIDETR_E_BADARG,
+                     "msda_fused: only channels == 32 (got %d), <= %d levels, L*P <= 256", D, kMaxLevels);
+    SEMIDETR_REQUIRE((((uintptr_t)value | (uintptr_t)off) & 15) == 0, SEMIDETR_E_BADARG,
+                     "msda_fused: value / sampling_offsets must be 16-byte aligned");
+    return SEMIDETR_OK;
+}
+
+extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                               const int64_t *level_start, const float *reference_points,
+                                               int ref_dim, const float *sampling_offsets,
+                                               const float *attn_logits, int batch, int spatial_size,
+                                               int num_heads, int channels, int num_levels, int num_query,
+                                               int num_point, float *out)
+{
+    if (int rc = check_fused(value, spatial_shapes, level_start, reference_points, ref_dim, sampling_offsets,
+                             attn_logits, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
+        return rc;
+    SEMIDETR_REQUIRE(out && ((uintptr_t)out & 15) == 0, SEMIDETR_E_BADARG, "msda_fused_forward: bad output pointer");
+    const RawIO io = {reference_points, sampling_offsets, attn_logits, nullptr, nullptr, ref_dim, num_heads,
+                      num_levels};
+    return launch_fast_forward(semidetr::as_stream(stream), value, spatial_shapes, level_start, io, batch,
+                               spatial_size, num_heads, num_levels, num_query, num_point, out);
+}
+
+extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const float *value,
+                                                const int64_t *spatial_shapes, const int64_t *level_start,
+                                                const float *reference_points, int ref_dim,
+                                                const float *sampling_offsets, const float *attn_logits, int batch,
+                                                int spatial_size, int num_heads, int channels, int num_levels,
+                                                int num_query, int num_point, float *grad_value,
+                                                float *grad_sampling_offsets, float *grad_attn_logits)
+{
+    if (int rc = check_fused(value, spatial_shapes, level_start, reference_points, ref_dim, sampling_offsets,
+                             attn_logits, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
+        return rc;
+    SEMIDETR_REQUIRE(grad_out && grad_value && grad_sampling_offsets && grad_attn_logits, SEMIDETR_E_BADARG,
+                     "msda_fused_backward: null pointer argument");
+    SEMIDETR_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_value | (uintptr_t)grad_sampling_offsets) & 15) == 0,
+                     SEMIDETR_E_BADARG, "msda_fused_backward: pointers must be 16-byte aligned");
+    const RawIO io = {reference_points, sampling_offsets, attn_logits, grad_sampling_offsets, grad_attn_logits,
+                      ref_dim, num_heads, num_levels};
+    return launch_fast_backward(semidetr::as_stream(stream), grad_out, value, spatial_shapes, level_start, io, batch,
+                                spatial_size, num_heads, num_levels, num_query, num_point, grad_value);
+}
+
+extern "C" int semidetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,
+                                         const int64_t *level_start, const double *sampling_loc,
+                                         const double *attn_weight, int batch, int spatial_size,
+                                         int num_heads, int channels, int num_levels, int num_query,
+                                         int num_point, double *out)
+{
+    return forward_impl<double>(stream, value, spatial_shapes, level_start, sampling_loc, attn_weight, batch,
+                                spatial_size, num_heads, channels, num_levels, num_query, num_point, out);
 }
 
 extern "C" int semidetr_msda_backward_f64(void *stream, const double *grad_out, const double *value,

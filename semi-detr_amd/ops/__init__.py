@@ -1,3 +1,3 @@
 """Mirror of the reference's ``detr_od/models/utils/ops`` package layout (functions/, modules/)."""
-from .functions import MSDeformAttnFunction  # noqa: F401
+from .functions import MSDeformAttnFunction, MSDeformAttnFusedFunction  # noqa: F401
 from .modules import MSDeformAttn  # noqa: F401

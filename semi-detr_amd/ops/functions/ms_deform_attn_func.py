@@ -8,6 +8,7 @@ The reference's pure-PyTorch debug routine (``ms_deform_attn_core_pytorch``, :41
 NOT part of this package: the product has no second implementation to fall back to; the CPU checker
 lives under ``oracle/`` and is test infrastructure.
 """
+import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
@@ -33,3 +34,38 @@ class MSDeformAttnFunction(Function):
             value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
             grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+
+
+class MSDeformAttnFusedFunction(Function):
+    """MSDeformAttn.forward between the Linear layers as ONE op: consumes the
+    reference points, the raw sampling offsets and the raw attention logits; softmax, location arithmetic
+    (detr_od/models/utils/ops/modules/ms_deform_attn.py:99-111) and their backward run inside the gfx950 kernels.
+    ``apply(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits)``."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits):
+        output = MSDA.ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points,
+                                                   sampling_offsets, attn_logits)
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                              attn_logits)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, ref, off, logits = ctx.saved_tensors
+        grad_value, grad_off, grad_logits = MSDA.ms_deform_attn_fused_backward(
+            value, shapes, starts, ref, off, logits, grad_output.contiguous())
+        grad_ref = None
+        if ctx.needs_input_grad[3]:
+            # d loc / d ref: the chain rule through the (elementwise) location arithmetic, from grad_off
+            L, P = off.shape[3], off.shape[4]
+            if ref.shape[-1] == 2:      # loc = ref + off / (W, H)  ->  d/d ref = sum_{m,p} grad_off * (W, H)
+                norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).to(off.dtype)          # (L, 2)
+                grad_ref = (grad_off * norm[None, None, None, :, None, :]).sum((2, 4))
+            else:                       # loc = ref_xy + off / P * ref_wh * 0.5
+                wh = ref[:, :, None, :, None, 2:]
+                scale = 0.5 * wh / P
+                grad_loc = torch.where(scale != 0, grad_off / scale, torch.zeros_like(grad_off))
+                grad_ref = torch.cat([grad_loc.sum((2, 4)), (grad_loc * off * (0.5 / P)).sum((2, 4))], -1)
+        return grad_value, None, None, grad_ref, grad_off, grad_logits

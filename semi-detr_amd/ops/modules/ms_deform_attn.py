@@ -14,7 +14,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions import MSDeformAttnFunction
+from ... import MultiScaleDeformableAttention as MSDA
+from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction
 
 
 def _is_power_of_2(n):
@@ -33,6 +34,11 @@ class MSDeformAttn(nn.Module):
                           "generic kernel; 32 channels per head is the tuned gfx950 path."
                           .format(d_model // n_heads))
         self.im2col_step = 64        # kept for config/state compatibility; one launch covers the batch
+        # Fuse softmax + location arithmetic (and their backward) into the sampling kernels whenever the
+        # configuration allows it (fp32, 32 channels per head): same results, none of the (N,Lq,M,L,P[,2])
+        # intermediates in HBM.  Not a parameter / buffer -> state_dict is unchanged.  Set False for the
+        # reference's op-by-op sequence.
+        self.fuse_prologue = True
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
 
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
@@ -73,7 +79,16 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
         offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Len_q, M, L * P), -1).view(N, Len_q, M, L, P)
+        logits = self.attention_weights(query).view(N, Len_q, M, L * P)
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead."
+                             .format(reference_points.shape[-1]))
+        if self.fuse_prologue and MSDA.fused_supported(value, reference_points, offsets, logits):
+            output = MSDeformAttnFusedFunction.apply(value.contiguous(), input_spatial_shapes,
+                                                     input_level_start_index, reference_points.contiguous(),
+                                                     offsets.contiguous(), logits.contiguous())
+            return self.output_proj(output)
+        weights = F.softmax(logits, -1).view(N, Len_q, M, L, P)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
             locations = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
