@@ -166,6 +166,19 @@ int semidetr_lsap_solve(void *stream, const float *cost, const int32_t *gt_offse
                         int64_t *assigned_gt_inds, int64_t *assigned_labels, int32_t *status,
                         void *workspace);
 
+/* Training targets of all problems from their assignment, one launch.
+ * Replaces the tail of  _get_target_single   detr_od/models/dense_heads/dino_detr_ssod_head.py:1170-1205,
+ *                                            detr_od/models/dense_heads/dino_detr_head.py:937-980
+ *           with PseudoSampler               thirdparty/mmdetection/mmdet/core/bbox/samplers/pseudo_sampler.py:35-41
+ *   assigned_gt_inds (B,Q) int64 from semidetr_lsap_solve; gt_bboxes / gt_labels / gt_offsets / img_wh as above.
+ *   labels (B,Q) int64 = num_classes for background else the gt label; label_weights (B,Q) = 1;
+ *   bbox_targets (B,Q,4) = cxcywh(gt / (w,h,w,h)) for positives else 0; bbox_weights (B,Q,4) = 1 / 0;
+ *   num_pos (B,) int32 (zeroed inside the call). */
+int semidetr_build_targets(void *stream, const int64_t *assigned_gt_inds, const float *gt_bboxes,
+                           const int64_t *gt_labels, const int32_t *gt_offsets, const float *img_wh,
+                           int num_problems, int num_query, int64_t num_classes, int64_t *labels,
+                           float *label_weights, float *bbox_targets, float *bbox_weights, int32_t *num_pos);
+
 /* ---------------------------------------------------------------------------------------------
  * Mean-teacher EMA, one launch for the whole parameter list.
  *

@@ -36,6 +36,7 @@ SIGNATURES = {
     "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
     "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "semidetr_lsap_solve": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 6),
+    "semidetr_build_targets": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int64] + [c_void_p] * 5),
     "semidetr_ema_multi_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_double]),
     "semidetr_ema_flat_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_double]),
     "semidetr_pseudo_label_filter_f32": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 6),

@@ -197,6 +197,44 @@ __global__ __launch_bounds__(64) void lsap_kernel(
 
 constexpr size_t kLdsLimit = 64 * 1024;
 
+// Training targets from the assignment, all problems in one launch:
+// dino_detr_ssod_head.py:1170-1205 / dino_detr_head.py:937-980 with PseudoSampler
+// (thirdparty/mmdetection/mmdet/core/bbox/samplers/pseudo_sampler.py:35-41):
+//   labels = num_classes (background) except labels[pos] = gt_labels[gt_inds[pos]-1]; label_weights = 1;
+//   bbox_targets[pos] = cxcywh(gt_bboxes[gt_inds[pos]-1] / (w,h,w,h)); bbox_weights[pos] = 1; num_pos per problem.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void build_targets_kernel(
+    const int64_t *__restrict__ gt_inds, const float *__restrict__ gt_bboxes, const int64_t *__restrict__ gt_labels,
+    const int32_t *__restrict__ gt_offsets, const float *__restrict__ img_wh, int Q, int64_t num_classes,
+    int64_t *__restrict__ labels, float *__restrict__ label_weights, float *__restrict__ bbox_targets,
+    float *__restrict__ bbox_weights, int32_t *__restrict__ num_pos)
+{
+    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    bool pos = false;
+    if (q < Q) {
+        const int64_t o = (int64_t)b * Q + q;
+        const int64_t gi = gt_inds[o];
+        pos = gi > 0;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t lab = num_classes;
+        if (pos) {
+            const int64_t g = gt_offsets[b] + gi - 1;
+            const float4 bx = *reinterpret_cast<const float4 *>(gt_bboxes + g * 4);
+            const float w = img_wh[2 * b], h = img_wh[2 * b + 1];
+            const float x1 = bx.x / w, y1 = bx.y / h, x2 = bx.z / w, y2 = bx.w / h;
+            t = make_float4((x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1);
+            lab = gt_labels[g];
+        }
+        labels[o] = lab;
+        label_weights[o] = 1.f;
+        *reinterpret_cast<float4 *>(bbox_targets + o * 4) = t;
+        const float wgt = pos ? 1.f : 0.f;
+        *reinterpret_cast<float4 *>(bbox_weights + o * 4) = make_float4(wgt, wgt, wgt, wgt);
+    }
+    const int n = __popcll(__ballot(pos));
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(&num_pos[b], n);
+}
+
 }  // namespace
 
 extern "C" int64_t semidetr_lsap_workspace_bytes(int num_problems, int num_query, int max_gt)
@@ -237,4 +275,26 @@ extern "C" int semidetr_lsap_solve(void *stream, const float *cost, const int32_
                            assigned_labels, status, (char *)workspace, per);
     }
     return semidetr::launch_status("lsap_kernel");
+}
+
+extern "C" int semidetr_build_targets(void *stream, const int64_t *assigned_gt_inds, const float *gt_bboxes,
+                                      const int64_t *gt_labels, const int32_t *gt_offsets, const float *img_wh,
+                                      int num_problems, int num_query, int64_t num_classes, int64_t *labels,
+                                      float *label_weights, float *bbox_targets, float *bbox_weights,
+                                      int32_t *num_pos)
+{
+    SEMIDETR_REQUIRE(num_problems >= 0 && num_query >= 0, SEMIDETR_E_BADARG, "build_targets: negative sizes");
+    if (num_problems == 0) return SEMIDETR_OK;
+    SEMIDETR_REQUIRE(assigned_gt_inds && gt_offsets && img_wh && labels && label_weights && bbox_targets &&
+                         bbox_weights && num_pos,
+                     SEMIDETR_E_BADARG, "build_targets: null pointer argument");
+    SEMIDETR_REQUIRE(num_problems <= 65535, SEMIDETR_E_TOOLARGE, "build_targets: more than 65535 problems");
+    hipStream_t st = semidetr::as_stream(stream);
+    hipError_t e = hipMemsetAsync(num_pos, 0, sizeof(int32_t) * (size_t)num_problems, st);
+    if (e != hipSuccess) return semidetr::fail((int)e, "build_targets memset: %s", hipGetErrorString(e));
+    if (num_query == 0) return SEMIDETR_OK;
+    hipLaunchKernelGGL(build_targets_kernel, dim3((num_query + 255) / 256, num_problems), dim3(256), 0, st,
+                       assigned_gt_inds, gt_bboxes, gt_labels, gt_offsets, img_wh, num_query, num_classes, labels,
+                       label_weights, bbox_targets, bbox_weights, num_pos);
+    return semidetr::launch_status("build_targets_kernel");
 }

@@ -62,11 +62,20 @@ def _params(cls_weight=0.0, alpha=0.25, gamma=2.0, eps=1e-12, reg_weight=0.0, bo
                            int(bool(pred_xyxy)))
 
 
+def _to_device_async(values, dtype, device):
+    """Small host list -> device tensor without a stream synchronisation (pinned staging + async copy); a
+    plain ``torch.tensor(list, device=...)`` is a blocking copy that drains the stream on every call."""
+    host = torch.tensor(values, dtype=dtype)
+    if device.type == "cuda":
+        return host.pin_memory().to(device, non_blocking=True)
+    return host.to(device)
+
+
 def _offsets(counts, device):
     offs = [0]
     for c in counts:
         offs.append(offs[-1] + int(c))
-    return offs, torch.tensor(offs, dtype=torch.int32, device=device)
+    return offs, _to_device_async(offs, torch.int32, device)
 
 
 def match_cost_batch(bbox_pred, cls_pred, gt_bboxes, gt_labels, gt_counts, img_wh, params):
@@ -251,8 +260,8 @@ class HungarianAssigner:
         counts = [int(g.size(0)) for g in gt_bboxes_list]
         gt_b = torch.cat([g.reshape(-1, 4) for g in gt_bboxes_list]) if B else bbox_preds.new_zeros((0, 4))
         gt_l = torch.cat([g.reshape(-1).long() for g in gt_labels_list]) if B else bbox_preds.new_zeros(0).long()
-        wh = torch.tensor([[m["img_shape"][1], m["img_shape"][0]] for m in img_metas], dtype=torch.float32)
-        cost, offs_dev, offs = match_cost_batch(bbox_preds, cls_preds, gt_b, gt_l, counts, wh.to(dev),
+        wh = _to_device_async([[m["img_shape"][1], m["img_shape"][0]] for m in img_metas], torch.float32, dev)
+        cost, offs_dev, offs = match_cost_batch(bbox_preds, cls_preds, gt_b, gt_l, counts, wh,
                                                 self._cost_params())
         res = lsap_batch(cost, offs_dev, offs, Q, gt_labels=gt_l, want_pairs=return_cost)
         if check:
@@ -267,6 +276,37 @@ class HungarianAssigner:
             costs = [cost[Q * offs[b]:Q * offs[b + 1]].view(counts[b], Q).t() for b in range(B)]
             return out, costs, res
         return out
+
+    def get_targets_batch(self, bbox_preds, cls_preds, gt_bboxes_list, gt_labels_list, img_metas, num_classes,
+                          check=True):
+        """Assignment + training targets of all problems, device-resident: what ``get_targets`` /
+        ``_get_target_single`` (dino_detr_ssod_head.py:987-1205, Hungarian branch) produce per (layer, image),
+        stacked.  Returns dict(labels (B,Q), label_weights (B,Q), bbox_targets (B,Q,4), bbox_weights (B,Q,4),
+        num_pos (B,) int32, gt_inds (B,Q), status).  pos_inds / neg_inds of problem b are
+        ``(gt_inds[b] > 0).nonzero()`` / ``(gt_inds[b] == 0).nonzero()`` when a caller wants index lists."""
+        B, Q = bbox_preds.shape[0], bbox_preds.shape[1]
+        dev = bbox_preds.device
+        counts = [int(g.size(0)) for g in gt_bboxes_list]
+        gt_b = torch.cat([g.reshape(-1, 4) for g in gt_bboxes_list]).to(torch.float32).contiguous()
+        gt_l = torch.cat([g.reshape(-1).long() for g in gt_labels_list]).contiguous()
+        wh = _to_device_async([[m["img_shape"][1], m["img_shape"][0]] for m in img_metas], torch.float32, dev)
+        cost, offs_dev, offs = match_cost_batch(bbox_preds, cls_preds, gt_b, gt_l, counts, wh, self._cost_params())
+        res = lsap_batch(cost, offs_dev, offs, Q, gt_labels=gt_l, want_pairs=False)
+        labels = torch.empty((B, Q), dtype=torch.int64, device=dev)
+        label_weights = torch.empty((B, Q), dtype=torch.float32, device=dev)
+        bbox_targets = torch.empty((B, Q, 4), dtype=torch.float32, device=dev)
+        bbox_weights = torch.empty((B, Q, 4), dtype=torch.float32, device=dev)
+        num_pos = torch.empty(B, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().semidetr_build_targets(
+                _lib.current_stream_ptr(), _p(res["gt_inds"]), _p(gt_b), _p(gt_l), _p(offs_dev), _p(wh), B, Q,
+                ctypes.c_int64(int(num_classes)), _p(labels), _p(label_weights), _p(bbox_targets), _p(bbox_weights),
+                _p(num_pos))
+        _lib.check(rc, "semidetr_build_targets")
+        if check:
+            raise_on_status(res["status"])
+        return dict(labels=labels, label_weights=label_weights, bbox_targets=bbox_targets,
+                    bbox_weights=bbox_weights, num_pos=num_pos, gt_inds=res["gt_inds"], status=res["status"])
 
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None, eps=1e-7):
         assert gt_bboxes_ignore is None, "Only case when gt_bboxes_ignore is None is supported."

@@ -162,3 +162,41 @@ def test_assign_batch_ragged_like_a_loss_call():
         gi, lab, _, _ = oracle.hungarian_assign(bp[b], cp[b], gts[b], labs[b], metas[b]["img_shape"][1], 800)
         assert np.array_equal(res[b].gt_inds.cpu().numpy(), gi), b
         assert np.array_equal(res[b].labels.cpu().numpy(), lab), b
+
+
+def test_get_targets_batch_matches_reference_semantics():
+    """SURVEY.md B.5 (dino_detr_ssod_head.py:1170-1205 + PseudoSampler): labels / weights / bbox targets of all
+    (layer, image) problems in one go, bit-exact against a numpy restatement on the oracle's assignment."""
+    from semi_detr_amd import HungarianAssigner
+    rng = np.random.default_rng(5)
+    B, Q, C = 14, 900, 80
+    counts = [int(x) for x in rng.integers(0, 12, B)]
+    counts[2] = 0
+    bp = np.concatenate([rng.random((B, Q, 2)), rng.random((B, Q, 2)) * 0.5 + 0.01], -1).astype(np.float32)
+    cp = (rng.standard_normal((B, Q, C)) * 3).astype(np.float32)
+    gts, labs, metas = [], [], []
+    for b in range(B):
+        xy = rng.random((counts[b], 2)) * [1000, 600]
+        gts.append(np.concatenate([xy, xy + rng.random((counts[b], 2)) * [300, 200] + 16], -1).astype(np.float32))
+        labs.append(rng.integers(0, C, counts[b]).astype(np.int64))
+        metas.append(dict(img_shape=(800, 1333 - 11 * (b % 2), 3)))
+    asg = HungarianAssigner(**DINO_ASSIGNER)
+    t = asg.get_targets_batch(_t(bp), _t(cp), [_t(g) for g in gts], [_t(l) for l in labs], metas, num_classes=C)
+    for b in range(B):
+        w, h = np.float32(metas[b]["img_shape"][1]), np.float32(800)
+        gi, _, _, _ = oracle.hungarian_assign(bp[b], cp[b], gts[b], labs[b], float(w), 800.0)
+        pos = np.nonzero(gi > 0)[0]
+        labels = np.full(Q, C, np.int64)
+        labels[pos] = labs[b][gi[pos] - 1]
+        bt = np.zeros((Q, 4), np.float32)
+        bw = np.zeros((Q, 4), np.float32)
+        g = gts[b][gi[pos] - 1] / np.array([w, h, w, h], np.float32)
+        bt[pos] = np.stack([(g[:, 0] + g[:, 2]) / np.float32(2), (g[:, 1] + g[:, 3]) / np.float32(2),
+                            g[:, 2] - g[:, 0], g[:, 3] - g[:, 1]], -1)
+        bw[pos] = 1
+        assert np.array_equal(t["gt_inds"][b].cpu().numpy(), gi)
+        assert np.array_equal(t["labels"][b].cpu().numpy(), labels)
+        assert np.array_equal(t["bbox_targets"][b].cpu().numpy(), bt)
+        assert np.array_equal(t["bbox_weights"][b].cpu().numpy(), bw)
+        assert np.all(t["label_weights"][b].cpu().numpy() == 1)
+        assert int(t["num_pos"][b]) == len(pos) == min(Q, counts[b])
