@@ -1,0 +1,704 @@
+// Fast-path device code of the multi-scale deformable attention for gfx950 (fp32, 32 channels per head):
+// IO policies (reference op contract / fused MSDeformAttn prologue), forward, plain backward, and the
+// gather + owner-computes scatter pair used for encoder self-attention.  Included by msda.hip only (inside
+// its anonymous namespace); see msda.hip for the shared sample geometry and the host-side dispatch.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// Where a fast-path kernel gets the (x, y, attention) of a sample from, and where the backward puts the two
+// small gradients.  LocAttnIO is the reference op contract.  RawIO is the fused prologue/epilogue of
+// MSDeformAttn.forward (detr_od/models/utils/ops/modules/ms_deform_attn.py:94-111): the kernels consume the
+// reference points, the RAW sampling offsets and the RAW attention logits (the outputs of the two Linear
+// layers) and do the softmax over L*P and the location arithmetic themselves, so the (N,Lq,M,L,P[,2])
+// intermediates (and their backward) never touch HBM.
+// ---------------------------------------------------------------------------------------------
+struct LocAttnIO {
+    const float *loc, *attn;
+    float *gloc, *gattn;
+    static constexpr bool kSoftmax = false;      // attn already holds probabilities
+    __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                            float &x, float &y) const
+    {
+        (void)nq; (void)l; (void)P; (void)H; (void)W;
+        const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + k) * 2);
+        x = xy.x;
+        y = xy.y;
+    }
+    __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return attn[row * LP + k]; }
+    // res = {d/d attn, d/d loc.x, d/d loc.y, attn} of sample k; row_res = the LP results of the same (n,q,m) row
+    __device__ __forceinline__ void store(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                          const float4 res, const float4 *row_res) const
+    {
+        (void)nq; (void)l; (void)P; (void)H; (void)W; (void)row_res;
+        gattn[row * LP + k] = res.x;
+        *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
+    }
+};
+
+struct RawIO {
+    const float *ref, *off, *logit;      // (N,Lq,L,ref_dim), (N,Lq,M,L,P,2), (N,Lq,M,L*P)
+    float *goff, *glogit;
+    int ref_dim, M, L;
+    static constexpr bool kSoftmax = true;       // load_w returns a raw logit; the kernel normalises the row
+    __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                            float &x, float &y) const
+    {
+        const float *rp = ref + (nq * L + l) * ref_dim;
+        const float2 o = *reinterpret_cast<const float2 *>(off + (row * LP + k) * 2);
+        if (ref_dim == 2) {          // ms_deform_attn.py:102-105
+            x = rp[0] + o.x / (float)W;
+            y = rp[1] + o.y / (float)H;
+        } else {                     // ms_deform_attn.py:106-108
+            x = rp[0] + o.x / (float)P * rp[2] * 0.5f;
+            y = rp[1] + o.y / (float)P * rp[3] * 0.5f;
+        }
+    }
+    __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return logit[row * LP + k]; }
+    // called by the LP consecutive threads that own the row's samples (see row_softmax)
+    __device__ __forceinline__ void store(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                          const float4 res, const float4 *row_res) const
+    {
+        float dot = res.w * res.x;               // softmax backward: a_k * (g_k - sum_j a_j g_j)
+        if ((LP & (LP - 1)) == 0 && LP <= 64) {
+            for (int d = 1; d < LP; d <<= 1) dot += __shfl_xor(dot, d, 64);
+        } else {                                 // generic LP: every thread re-reads the row (rare)
+            dot = 0.f;
+            for (int j = 0; j < LP; ++j) dot += row_res[j].w * row_res[j].x;
+        }
+        glogit[row * LP + k] = res.w * (res.x - dot);
+        float2 g;
+        if (ref_dim == 2) {
+            g = make_float2(res.y / (float)W, res.z / (float)H);
+        } else {
+            const float *rp = ref + (nq * L + l) * ref_dim;
+            g = make_float2(res.y * 0.5f * rp[2] / (float)P, res.z * 0.5f * rp[3] / (float)P);
+        }
+        *reinterpret_cast<float2 *>(goff + (row * LP + k) * 2) = g;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// fast path: fp32, D == 32.  8 lanes x float4 per 128-byte value row.
+// ---------------------------------------------------------------------------------------------
+constexpr int kD = 32;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x)
+{
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// sum over the 8 lanes of a group: quad xor1, quad xor2, then mirror inside the half-row (i <-> 7-i).
+__device__ __forceinline__ float group8_sum(float x)
+{
+    x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);  // row_half_mirror
+    return x;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p, int off)
+{
+    return off >= 0 ? *reinterpret_cast<const float4 *>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Softmax over the L*P logits of one (n, q, m) row (ms_deform_attn.py:101), evaluated cooperatively by the LP
+// consecutive threads that own the row's samples: one expf per sample, max / sum by xor-shuffles when LP is a
+// power of two <= 64 (the DINO case LP = 16 is one DPP row); any other LP falls back to a per-thread loop.
+template <typename IO>
+__device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, int k, float raw)
+{
+    if (!IO::kSoftmax) return raw;
+    if ((LP & (LP - 1)) == 0 && LP <= 64) {
+        float mx = raw;
+        for (int d = 1; d < LP; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        const float e = expf(raw - mx);
+        float sum = e;
+        for (int d = 1; d < LP; d <<= 1) sum += __shfl_xor(sum, d, 64);
+        return e / sum;
+    }
+    float mx = raw;
+    for (int j = 0; j < LP; ++j) mx = fmaxf(mx, io.load_w(row, LP, j));
+    float sum = 0.f;
+    for (int j = 0; j < LP; ++j) sum += expf(io.load_w(row, LP, j) - mx);
+    (void)k;
+    return expf(raw - mx) / sum;
+}
+
+// Workgroup -> (n, query tile, m): m fastest so that blockIdx % 8 == m % 8 when M % 8 == 0 (L2 affinity,
+// speed only -- correctness never depends on placement).
+struct Tile {
+    int n, q0, m;
+};
+__device__ __forceinline__ Tile tile_of_block(int M, int tiles_per_image, int rows_per_block)
+{
+    const int b = blockIdx.x;
+    Tile t;
+    t.m = b % M;
+    const int r = b / M;
+    t.q0 = (r % tiles_per_image) * rows_per_block;
+    t.n = r / tiles_per_image;
+    return t;
+}
+
+// Encoder self-attention (num_query == spatial_size: query i IS pixel i of the multi-scale map): instead of
+// 32 consecutive pixels (a 32 x 1 strip) a workgroup can take a PH x PW patch of one level -- its samples
+// then land in a (PH + margin) x (PW + margin) neighbourhood on every level instead of a long thin one, which
+// roughly halves the distinct value rows a workgroup pulls through its L1.  Patches are enumerated on the
+// device because the level table lives in device memory; `tile` indexes them level by level.
+struct Patch {
+    int Hq, Wq, stq, y0, x0;     // level of the patch's queries and its top-left pixel; Hq == 0: no such patch
+};
+template <int PH, int PW>
+__device__ __forceinline__ Patch find_patch(int tile, const int64_t *shapes, const int64_t *starts, int L)
+{
+    Patch p = {0, 0, 0, 0, 0};
+    int acc = 0;
+    for (int l = 0; l < L; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const int nx = (W + PW - 1) / PW, nt = ((H + PH - 1) / PH) * nx;
+        if (tile < acc + nt) {
+            p.Hq = H; p.Wq = W; p.stq = (int)starts[l];
+            p.y0 = ((tile - acc) / nx) * PH; p.x0 = ((tile - acc) % nx) * PW;
+            return p;
+        }
+        acc += nt;
+    }
+    return p;
+}
+template <int PW>
+__device__ __forceinline__ int patch_query(const Patch &p, int r)      // r-th query of the patch or -1
+{
+    const int y = p.y0 + r / PW, x = p.x0 + r % PW;
+    return (y < p.Hq && x < p.Wq) ? p.stq + y * p.Wq + x : -1;
+}
+
+// SPLIT = number of 8-lane groups that share one (q) row; each takes samples k = part, part+SPLIT, ...
+template <int SPLIT, int UNROLL, int PATCH = 0, typename IO = LocAttnIO>
+__global__ __launch_bounds__(256) void msda_fwd_d32(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ out)
+{
+    constexpr int RPB = 32 / SPLIT;   // query rows per workgroup
+    extern __shared__ float4 smem[];
+    const int LP = L * P, LPP = LP + 1;   // +1 record of padding: rows land on different LDS banks
+    int4 *rec_off = reinterpret_cast<int4 *>(smem);
+    float4 *rec_w = smem + RPB * LPP;
+
+    Tile t = tile_of_block(M, tiles_per_image, RPB);
+    const int rs = M * kD;
+    constexpr int PH = PATCH / 100, PW = PATCH % 100;
+    static_assert(PATCH == 0 || (PH * PW == RPB && SPLIT == 1), "a patch holds exactly the workgroup's rows");
+    Patch pt = {0, 0, 0, 0, 0};
+    // PATCH: tiles_per_image is only a sizing hint for the grid -- a workgroup takes patches slot, slot + hint,
+    // ... until the pyramid is exhausted, so any hint >= 1 is correct (the level table is device memory).
+    for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
+    if (PATCH) {
+        pt = find_patch<PH ? PH : 1, PW ? PW : 1>(tile, shapes, starts, L);
+        if (pt.Hq == 0) return;
+        __syncthreads();      // previous patch done with the LDS records
+    }
+    auto query_of = [&](int r) { return PATCH ? patch_query<PW ? PW : 1>(pt, r) : (t.q0 + r < Lq ? t.q0 + r : -1); };
+
+    // ---- phase 1: sample records -------------------------------------------------------------
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int r = s / LP, k = s - r * LP;
+        const int q = query_of(r);
+        int off[4] = {-1, -1, -1, -1};
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q >= 0) {
+            const int l = k / P;
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
+            float x, y, lw, lh;
+            io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
+            const float a = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                w = make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw));
+            }
+        }
+        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_w[r * LPP + k] = w;
+    }
+    __syncthreads();
+
+    // ---- phase 2: gather + weighted sum ------------------------------------------------------
+    const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int r = g / SPLIT, part = g % SPLIT;
+    const int q = query_of(r);
+    const float *vb = value + ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int4 *ro = rec_off + r * LPP;
+    const float4 *rw = rec_w + r * LPP;
+#pragma unroll UNROLL
+    for (int k = part; k < LP; k += SPLIT) {
+        const int4 o = ro[k];
+        const float4 w = rw[k];
+        const float4 v1 = ld4(vb, o.x), v2 = ld4(vb, o.y), v3 = ld4(vb, o.z), v4 = ld4(vb, o.w);
+        acc.x += w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
+        acc.y += w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
+        acc.z += w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
+        acc.w += w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
+    }
+    if (SPLIT > 1) {
+#pragma unroll
+        for (int s = 8; s < 8 * SPLIT; s <<= 1) {
+            acc.x += __shfl_xor(acc.x, s, 64);
+            acc.y += __shfl_xor(acc.y, s, 64);
+            acc.z += __shfl_xor(acc.z, s, 64);
+            acc.w += __shfl_xor(acc.w, s, 64);
+        }
+    }
+    if (part == 0 && q >= 0) {
+        const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
+        *reinterpret_cast<float4 *>(out + row * kD + 4 * j) = acc;
+    }
+    if (!PATCH) return;
+    }
+}
+
+// Sum over the 32 lanes of each wavefront half (lane = channel).  After the five steps lanes 16..31 of
+// each half hold the half's total; the writer is lane 16 / 48.
+__device__ __forceinline__ float half32_sum(float x)
+{
+    x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);   // row_half_mirror
+    x += dpp_mov<0x140>(x);   // row_mirror  -> every lane of a 16-lane row holds the row total
+    // row_bcast:15 into rows 1 and 3 (row_mask 0xA): lane 15 of the previous row is added to every lane
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, true));
+    return x;
+}
+
+// Backward, fp32 / D == 32.  One value row (128 B) per 32 lanes, lane = channel: every global_atomic_add_f32
+// wave-instruction updates two COMPLETE cache lines.  Measured on MI355X (tools/atomic_probe.hip): L2 fp32
+// atomics cost ~one unit per 64-byte half-line touched (~20.8 G units/s chip-wide), so full-row updates move
+// 4x more gradient per unit than the 8-lane x float4 layout the forward uses.
+// RPB = query rows per 256-thread workgroup (8 half-waves, each walks RPB/8 rows).
+template <int RPB, typename IO = LocAttnIO>
+__global__ __launch_bounds__(256) void msda_bwd_d32(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image,
+    float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    const int LP = L * P, LPP = LP + 1;
+    int4 *rec_off = reinterpret_cast<int4 *>(smem);
+    float4 *rec_p = smem + RPB * LPP;   // {lw, lh, a, level} ; overwritten with {g_attn, g_x, g_y, -}
+    float *lev_w = reinterpret_cast<float *>(smem + 2 * RPB * LPP), *lev_h = lev_w + kMaxLevels;
+
+    const Tile t = tile_of_block(M, tiles_per_image, RPB);
+    const int rs = M * kD;
+    if (threadIdx.x < L) {
+        lev_h[threadIdx.x] = (float)shapes[2 * threadIdx.x];
+        lev_w[threadIdx.x] = (float)shapes[2 * threadIdx.x + 1];
+    }
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int r = s / LP, k = s - r * LP;
+        const int q = t.q0 + r;
+        int off[4] = {-1, -1, -1, -1};
+        const int l = k / P;
+        float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
+        if (q < Lq) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
+            float x, y, lw, lh;
+            io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
+            // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
+            pr.z = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+                pr.x = lw;
+                pr.y = lh;
+            }
+        }
+        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_p[r * LPP + k] = pr;
+    }
+    __syncthreads();
+
+    const int hw = threadIdx.x >> 5, c = threadIdx.x & 31;      // half-wave index, channel
+    const int64_t vo = ((int64_t)t.n * S * M + t.m) * kD + c;
+    const float *vb = value + vo;
+    float *gvb = gvalue + vo;
+    for (int r = hw; r < RPB; r += 8) {
+        const int q = t.q0 + r;
+        if (q >= Lq) break;
+        const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
+        const float go = gout[row * kD + c];
+        const int4 *ro = rec_off + r * LPP;
+        float4 *rp = rec_p + r * LPP;
+#pragma unroll 4
+        for (int k = 0; k < LP; ++k) {
+            const int4 o = ro[k];
+            const float4 pr = rp[k];
+            const float lw = pr.x, lh = pr.y, a = pr.z;
+            const int l = __float_as_int(pr.w);
+            const float hh = 1.f - lh, hwt = 1.f - lw;
+            const float ga = go * a;
+            float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+            if (o.x >= 0) v1 = vb[o.x];
+            if (o.y >= 0) v2 = vb[o.y];
+            if (o.z >= 0) v3 = vb[o.z];
+            if (o.w >= 0) v4 = vb[o.w];
+            if (o.x >= 0) fp_atomic_add(gvb + o.x, hh * hwt * ga);
+            if (o.y >= 0) fp_atomic_add(gvb + o.y, hh * lw * ga);
+            if (o.z >= 0) fp_atomic_add(gvb + o.z, lh * hwt * ga);
+            if (o.w >= 0) fp_atomic_add(gvb + o.w, lh * lw * ga);
+            float pa = go * (hh * hwt * v1 + hh * lw * v2 + lh * hwt * v3 + lh * lw * v4);
+            float px = ga * (hh * (v2 - v1) + lh * (v4 - v3));
+            float py = ga * (hwt * (v3 - v1) + lw * (v4 - v2));
+            pa = half32_sum(pa);
+            px = half32_sum(px);
+            py = half32_sum(py);
+            if (c == 16) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, a);
+        }
+    }
+    __syncthreads();
+
+    // ---- coalesced write-back of grad_attn_weight / grad_sampling_loc --------------------------
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int rr = s / LP, k = s - rr * LP;
+        const int qq = t.q0 + rr;
+        if (qq >= Lq) continue;
+        const int64_t nq = (int64_t)t.n * Lq + qq, row = nq * M + t.m;
+        const int l = k / P;
+        io.store(row, nq, LP, k, l, P, (int)lev_h[l], (int)lev_w[l], rec_p[rr * LPP + k], rec_p + rr * LPP);
+    }
+}
+
+
+// Gather half of the backward on its own (fp32, D == 32): grad_attn_weight and grad_sampling_loc for every
+// sample, NO grad_value scatter.  Same tiling / LDS records / 8-lane x float4 loads as msda_fwd_d32<1>; the
+// three channel sums per sample are 3 DPP steps inside the 8-lane group.  Streams like the forward (no
+// atomics, no per-level barriers), used together with the owner-computes scatter kernel below.
+template <typename IO = LocAttnIO>
+__global__ __launch_bounds__(256) void msda_bwd_gather_d32(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
+{
+    constexpr int RPB = 32;
+    extern __shared__ float4 smem[];
+    const int LP = L * P, LPP = LP + 1;
+    int4 *rec_off = reinterpret_cast<int4 *>(smem);
+    float4 *rec_p = smem + RPB * LPP;   // {lw, lh, a, level} ; overwritten with {g_attn, g_x, g_y, -}
+    float *lev_w = reinterpret_cast<float *>(smem + 2 * RPB * LPP), *lev_h = lev_w + kMaxLevels;
+
+    const Tile t = tile_of_block(M, tiles_per_image, RPB);
+    const int rs = M * kD;
+    if (threadIdx.x < L) {
+        lev_h[threadIdx.x] = (float)shapes[2 * threadIdx.x];
+        lev_w[threadIdx.x] = (float)shapes[2 * threadIdx.x + 1];
+    }
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int r = s / LP, k = s - r * LP;
+        const int q = t.q0 + r;
+        int off[4] = {-1, -1, -1, -1};
+        const int l = k / P;
+        float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
+        if (q < Lq) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
+            float x, y, lw, lh;
+            io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
+            // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
+            pr.z = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+                pr.x = lw;
+                pr.y = lh;
+            }
+        }
+        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_p[r * LPP + k] = pr;
+    }
+    __syncthreads();
+
+    const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int q = t.q0 + r;
+    const float *vb = value + ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < Lq) go = *reinterpret_cast<const float4 *>(gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j);
+    const int4 *ro = rec_off + r * LPP;
+    float4 *rp = rec_p + r * LPP;
+    // Batches of kGU samples, unrolled by hand: the result store into rec_p would otherwise keep the compiler
+    // from hoisting the next samples' record reads / corner loads above it (4 * kGU loads in flight per lane; measured on MI355X at the encoder shape: kGU 1 / 2 / 4 -> 438 / 508 / 643 us, so 1).
+    constexpr int kGU = 1;
+    for (int k0 = 0; k0 < LP; k0 += kGU) {
+        int4 o[kGU];
+        float4 pr[kGU], v[kGU][4];
+#pragma unroll
+        for (int u = 0; u < kGU; ++u) {
+            const int k = min(k0 + u, LP - 1);
+            o[u] = ro[k];
+            pr[u] = rp[k];
+        }
+#pragma unroll
+        for (int u = 0; u < kGU; ++u) {
+            v[u][0] = ld4(vb, o[u].x); v[u][1] = ld4(vb, o[u].y);
+            v[u][2] = ld4(vb, o[u].z); v[u][3] = ld4(vb, o[u].w);
+        }
+#pragma unroll
+        for (int u = 0; u < kGU; ++u) {
+            if (k0 + u >= LP) break;
+            const float lw = pr[u].x, lh = pr[u].y, a = pr[u].z;
+            const int l = __float_as_int(pr[u].w);
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+            const float4 v1 = v[u][0], v2 = v[u][1], v3 = v[u][2], v4 = v[u][3];
+            const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
+            float pa = go.x * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) +
+                       go.y * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) +
+                       go.z * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) +
+                       go.w * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
+            float px = ga.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) +
+                       ga.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
+                       ga.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) +
+                       ga.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
+            float py = ga.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) +
+                       ga.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
+                       ga.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) +
+                       ga.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
+            pa = group8_sum(pa);
+            px = group8_sum(px);
+            py = group8_sum(py);
+            if (j == 0) rp[k0 + u] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, a);
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+        const int rr = s / LP, k = s - rr * LP;
+        const int qq = t.q0 + rr;
+        if (qq >= Lq) continue;
+        const int64_t nq = (int64_t)t.n * Lq + qq, row = nq * M + t.m;
+        const int l = k / P;
+        io.store(row, nq, LP, k, l, P, (int)lev_h[l], (int)lev_w[l], rec_p[rr * LPP + k], rec_p + rr * LPP);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grad_value for encoder self-attention (num_query == spatial_size: the queries ARE the pixels of the
+// multi-scale map), fp32, D == 32, num_point == 4.  Runs after msda_bwd_gather_d32.
+//
+// The L2 atomic unit is the bottleneck of the plain backward (4 full-row atomics per sample; measured ceiling
+// 10.4 G full-row fp32 atomics/s chip-wide, tools/atomic_probe.hip), but in the encoder neighbouring queries
+// sample neighbouring pixels, so most of those atomics hit the same few rows.  LDS float atomics are no way
+// out: ds_add_f32 runs lane-serially on gfx950 (~97 clk per 32-lane row vs ~9 for ds_add_u32,
+// tools/lds_atomic_probe.hip).  So the scatter is turned into an OWNER-COMPUTES gather inside the workgroup,
+// using only integer LDS atomics:
+//   * a workgroup takes a TH x TW patch of query pixels of one level and one head; grad_out of the patch is
+//     staged in LDS once (128 rows x 128 B);
+//   * per sampling level it places a WH x WW window of value rows where the patch's own pixels map to on that
+//     level, and buckets every (sample, corner) pair that falls inside the window by target row:
+//     count (ds_add_rtn_u32) -> exclusive scan -> fill {corner weight x attention weight, row, query};
+//   * the bucketed entries are sorted by row; every half-wave (lane = channel) walks an equal share of them,
+//     keeps the running row sum  sum_i w_i * grad_out[q_i][c]  in a register and issues ONE full-line global
+//     atomic per row run;
+//   * corners outside the window (rare in the encoder) are put on a miss list and scattered one full-line
+//     atomic each, exactly like the plain kernel -- any sampling pattern is correct, locality only decides speed.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTH = 8, kTW = 16, kTQ = kTH * kTW;       // query patch: 8 x 16 pixels = 128 queries
+constexpr int kWH = 24, kWW = 32, kWR = kWH * kWW;      // window: 24 x 32 value rows = 768 counters
+constexpr int kWinThreads = 512;                        // 8 wavefronts = 16 half-waves
+constexpr int kPT = 4;                                  // num_point (compile time: one sample per thread)
+constexpr int kNE = kTQ * kPT * 4;                      // corners per (patch, level)
+
+template <typename IO = LocAttnIO>
+__global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int tiles_bound, float *__restrict__ gvalue)
+{
+    static_assert(kTQ * kPT == kWinThreads, "one (query, point) sample per thread");
+    static_assert(kWR <= 2 * kWinThreads, "scan assigns two counters per thread");
+    __shared__ float2 entries[kNE + 8];          // front: bucketed {weight, window row << 8 | query} (+8: batch
+                                                 //        reads may run past a share's end, results unused);
+                                                 // back : misses {weight, query << 25 | pixel index}
+    __shared__ float gtile[kTQ * kD];            // grad_out rows of the patch
+    __shared__ int cnt[kWR], start[kWR];
+    __shared__ int stats2[2][4], wsum[kWinThreads / 64];   // stats double-buffered by level parity: a fast
+                                                           // wavefront may start level l+1 while others still read l's
+
+    constexpr int P = kPT;
+    const int Lq = S, LP = L * P, rs = M * kD;
+    const int b = blockIdx.x;
+    const int m = b % M;
+    const int slot = (b / M) % tiles_bound, n = (b / M) / tiles_bound;
+    const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
+
+    for (int tile = slot;; tile += tiles_bound) {
+        // ---- which patch of which level is tile number `tile`? (uniform across the workgroup)
+        int lq = -1, acc = 0, ntx = 1, Hq = 0, Wq = 0, stq = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            const int nx = (W + kTW - 1) / kTW, nt = ((H + kTH - 1) / kTH) * nx;
+            if (tile < acc + nt) { lq = l; ntx = nx; Hq = H; Wq = W; stq = (int)starts[l]; break; }
+            acc += nt;
+        }
+        if (lq < 0) break;
+        const int ty = (tile - acc) / ntx, tx = (tile - acc) % ntx;
+        // this thread's sample = (query i, point p) of the patch
+        const int i = tid / P, p = tid - i * P;
+        const int qy = ty * kTH + i / kTW, qx = tx * kTW + i % kTW;
+        const int q = (qy < Hq && qx < Wq) ? stq + qy * Wq + qx : -1;
+        const int64_t srow = q >= 0 ? ((int64_t)n * Lq + q) * M + m : 0;
+        // patch centre in normalised coordinates (pixel centres are (i + 0.5) / size)
+        const float pcy = (ty * kTH + 0.5f * kTH) / (float)Hq, pcx = (tx * kTW + 0.5f * kTW) / (float)Wq;
+        // fused prologue: softmax statistics of this thread's (query, head) row, once per patch.  The row's L*P
+        // logits belong to the P threads of the query (a quad for P = 4), L each: quad reductions.
+        float sm_max = 0.f, sm_inv = 1.f;
+        if (IO::kSoftmax) {
+            float mx = -__builtin_huge_valf();
+            if (q >= 0)
+                for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow, LP, l * P + p));
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            float sum = 0.f;
+            if (q >= 0)
+                for (int l = 0; l < L; ++l) sum += expf(io.load_w(srow, LP, l * P + p) - mx);
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sm_max = mx;
+            sm_inv = 1.f / sum;
+        }
+        __syncthreads();                      // previous patch fully done before its LDS state is reused
+        for (int r = hw; r < kTQ; r += kWinThreads / 32) {      // stage grad_out of the patch, channels (c, c+16)
+            const int ry = ty * kTH + r / kTW, rx = tx * kTW + r % kTW;   // interleaved: lane l of a 16-lane stream
+            gtile[r * kD + (c & 15) * 2 + (c >> 4)] =                     // reads both with one ds_read_b64
+                (ry < Hq && rx < Wq) ? gout[(((int64_t)n * Lq + stq + ry * Wq + rx) * M + m) * kD + c] : 0.f;
+        }
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            // window: where the patch centre maps to on this level, minus half the window
+            const int y0 = (int)floorf(pcy * H - 0.5f) - kWH / 2 + 1;
+            const int x0 = (int)floorf(pcx * W - 0.5f) - kWW / 2 + 1;
+            int *stats = stats2[l & 1];
+            if (tid < 4) stats[tid] = 0;
+            for (int k = tid; k < kWR; k += kWinThreads) cnt[k] = 0;
+            // ---- this thread's sample geometry
+            int off[4] = {-1, -1, -1, -1};
+            float lw = 0.f, lh = 0.f, a = 0.f;
+            int h0 = 0, w0 = 0;
+            if (q >= 0) {
+                const int k = l * P + p;
+                float x, y;
+                io.load_xy(srow, (int64_t)n * Lq + q, LP, k, l, P, H, W, x, y);
+                if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+                    a = io.load_w(srow, LP, k);
+                    if (IO::kSoftmax) a = expf(a - sm_max) * sm_inv;
+                    // the top-left corner (h0, w0) exactly as sample_setup derived it
+                    h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
+                    w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
+                }
+            }
+            __syncthreads();                  // counters zeroed, previous level's walk finished
+            // ---- bucket the in-window corners by window row (count), list the others as misses
+            const int wy = h0 - y0, wx = w0 - x0;
+            const bool in_y0 = (unsigned)wy < (unsigned)kWH, in_y1 = (unsigned)(wy + 1) < (unsigned)kWH;
+            const bool in_x0 = (unsigned)wx < (unsigned)kWW, in_x1 = (unsigned)(wx + 1) < (unsigned)kWW;
+            const int wi = wy * kWW + wx;
+            const float hh = 1.f - lh, hwt = 1.f - lw;
+            const float cw[4] = {hh * hwt * a, hh * lw * a, lh * hwt * a, lh * lw * a};
+            const bool inw[4] = {in_y0 && in_x0, in_y0 && in_x1, in_y1 && in_x0, in_y1 && in_x1};
+            const int wrow[4] = {wi, wi + 1, wi + kWW, wi + kWW + 1};
+            int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                if (off[cidx] < 0) continue;
+                if (inw[cidx]) rank[cidx] = atomicAdd(&cnt[wrow[cidx]], 1);
+                else   // off = pixel index * rs: keep the pixel index (< 2^25, checked by the launcher) + the query
+                    entries[kNE - 1 - atomicAdd(&stats[1], 1)] =
+                        make_float2(cw[cidx], __int_as_float((int)(((unsigned)i << 25) | (unsigned)(off[cidx] / rs))));
+            }
+            __syncthreads();
+            // ---- exclusive scan of the kWR counters -> start[]  (thread t owns counters 2t, 2t+1)
+            {
+                const int j0 = tid * 2;
+                const int c0 = j0 < kWR ? cnt[j0] : 0, c1 = j0 + 1 < kWR ? cnt[j0 + 1] : 0;
+                const int v = c0 + c1;
+                int incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += t;
+                }
+                if (lane == 63) wsum[wv] = incl;
+                __syncthreads();
+                int base = 0;
+                for (int w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+                const int excl = base + incl - v;
+                if (j0 < kWR) start[j0] = excl;
+                if (j0 + 1 < kWR) start[j0 + 1] = excl + c0;
+                if (tid == kWinThreads - 1) stats[3] = excl + v;            // total number of bucketed entries
+            }
+            __syncthreads();
+            // ---- fill the buckets
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx)
+                if (off[cidx] >= 0 && inw[cidx])
+                    entries[start[wrow[cidx]] + rank[cidx]] = make_float2(cw[cidx], __int_as_float((wrow[cidx] << 8) | i));
+            __syncthreads();
+            // ---- owner computes: 32 streams of 16 lanes (lane l = channels l and l+16) each walk an equal share
+            //      of the row-sorted entries, keep the running row sum in two registers and flush a finished row
+            //      with two half-line atomics (64 contiguous bytes each = the same 2 atomic units as one full row)
+            {
+                constexpr int kStreams = kWinThreads / 16;
+                const int sid = tid >> 4, l16 = tid & 15;
+                const float2 *gt2 = reinterpret_cast<const float2 *>(gtile);
+                float *gvs = gvalue + ((int64_t)n * S * M + m) * kD + l16;
+                const int total = stats[3];
+                const int lo = (int)((int64_t)total * sid / kStreams);
+                const int hi = (int)((int64_t)total * (sid + 1) / kStreams);
+                int cur = -1;
+                float2 accv = make_float2(0.f, 0.f);
+                auto flush = [&](int rowi) {
+                    float *pr = gvs + (int64_t)(st + (y0 + rowi / kWW) * W + x0 + rowi % kWW) * rs;
+                    fp_atomic_add(pr, accv.x);
+                    fp_atomic_add(pr + 16, accv.y);
+                };
+                // software pipeline: 8 independent entry reads, then 8 independent grad_out reads, then the (short)
+                // dependent accumulate / row-change chain.  Full batches run without bounds checks.
+                auto step = [&](const float2 &en, const float2 &gq) {
+                    const int rowi = __float_as_int(en.y) >> 8;
+                    if (rowi != cur) {
+                        if (cur >= 0) flush(cur);
+                        cur = rowi;
+                        accv = make_float2(0.f, 0.f);
+                    }
+                    accv.x += en.x * gq.x;
+                    accv.y += en.x * gq.y;
+                };
+                int e = lo;
+                for (; e + 8 <= hi; e += 8) {
+                    float2 en[8], gq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) en[u] = entries[e + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 255) * 16 + l16];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) step(en[u], gq[u]);
+                }
+                if (e < hi) {       // tail of < 8 entries (reads stay inside the padded array)
+                    float2 en[8], gq[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) en[u] = entries[e + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 255) * 16 + l16];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (e + u < hi) step(en[u], gq[u]);
+                }
+                if (cur >= 0) flush(cur);
+                // ---- misses: one row update per (sample, corner), as the plain kernel does
+                const int nmiss = stats[1];
+                for (int mi = sid; mi < nmiss; mi += kStreams) {
+                    const float2 en = entries[kNE - 1 - mi];
+                    const int pk = __float_as_int(en.y);
+                    const float2 g2 = gt2[((unsigned)pk >> 25) * 16 + l16];
+                    float *pr = gvs + (int64_t)(pk & 0x1ffffff) * rs;
+                    fp_atomic_add(pr, en.x * g2.x);
+                    fp_atomic_add(pr + 16, en.x * g2.y);
+                }
+            }
+        }
+    }
+}
+
