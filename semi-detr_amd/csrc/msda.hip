@@ -65,6 +65,57 @@ __device__ __forceinline__ bool sample_setup(T x, T y, int H, int W, int start, 
     return true;
 }
 
+// Same geometry for the fast-path kernels that LOAD the corners, in the form the buffer instructions want:
+// off[i] = BYTE offset of corner i inside the image's value slice (head / channel offset not included), or
+// kOob for a corner outside the level / a skipped sample.  The kernels read the value map through a raw buffer
+// resource whose size is exactly one image slice: the hardware bounds check of buffer_load returns 0 for kOob,
+// which IS the op's zero padding -- no per-corner exec-mask branches, no zero-initialised destination
+// registers in the hot loop (they were 1/3 of its VALU instructions), and values elsewhere in memory can never
+// leak into a sample (NaN-safe exactly like the reference).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0xFFFFF000u;       // + any in-row lane offset (< 4096) stays out of range, no wrap
+
+__device__ __forceinline__ bool sample_setup_oob(float x, float y, int H, int W, int start, unsigned row_bytes,
+                                                 unsigned (&off)[4], float &lw, float &lh)
+{
+    const float h = sub_rn(mul_rn(y, (float)H), 0.5f);
+    const float w = sub_rn(mul_rn(x, (float)W), 0.5f);
+    off[0] = off[1] = off[2] = off[3] = kOob;
+    lw = lh = 0;
+    if (!(h > -1.f && w > -1.f && h < (float)H && w < (float)W)) return false;
+    const int h0 = (int)floorf(h), w0 = (int)floorf(w);
+    lh = sub_rn(h, (float)h0);
+    lw = sub_rn(w, (float)w0);
+    const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
+    const unsigned base = (unsigned)(start + h0 * W + w0) * row_bytes;     // may wrap for h0/w0 == -1: unused then
+    if (top && lef) off[0] = base;
+    if (top && rig) off[1] = base + row_bytes;
+    if (bot && lef) off[2] = base + (unsigned)W * row_bytes;
+    if (bot && rig) off[3] = base + (unsigned)(W + 1) * row_bytes;
+    return true;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const float *image_base, unsigned image_bytes)
+{
+    // The descriptor is wave-uniform (it depends on blockIdx only) but the compiler cannot prove it and would
+    // wrap every buffer op in a waterfall loop; readfirstlane of its inputs makes the uniformity explicit.
+    const unsigned long long b = reinterpret_cast<unsigned long long>(image_base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(image_bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, nb,
+                                             0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
 __device__ __forceinline__ void fp_atomic_add(float *p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void fp_atomic_add(double *p, double v) { unsafeAtomicAdd(p, v); }
 
@@ -230,6 +281,9 @@ bool fast_ok(const void *a, const void *b, const void *c, int D, int L, int P)
     return D == kD && L <= kMaxLevels && (al & 15) == 0 && (int64_t)L * P <= 256;
 }
 
+// the fast-path kernels address one image's value slice with 32-bit BYTE offsets (buffer instructions)
+bool slice_ok(int S, int M) { return (int64_t)S * M * kD * 4 < (int64_t)0xFFFFF000u; }
+
 int pick_split(int forced, int N, int Lq, int M)
 {
     if (forced == 1 || forced == 2 || forced == 4) return forced;
@@ -335,7 +389,7 @@ extern "C" int semidetr_msda_forward_f32(void *stream, const float *value, const
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query,
               P = num_point;
-    if (g_fwd_variant == 99 || !fast_ok(value, sampling_loc, out, D, L, P))
+    if (g_fwd_variant == 99 || !fast_ok(value, sampling_loc, out, D, L, P) || !slice_ok(S, M))
         return forward_impl<float>(stream, value, spatial_shapes, level_start, sampling_loc, attn_weight, N,
                                    S, M, D, L, Lq, P, out);
     if (int rc = check_common(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L,
@@ -356,7 +410,7 @@ extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, c
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query,
               P = num_point;
-    if (g_bwd_variant == 99 || !fast_ok(value, sampling_loc, grad_out, D, L, P) ||
+    if (g_bwd_variant == 99 || !fast_ok(value, sampling_loc, grad_out, D, L, P) || !slice_ok(S, M) ||
         !fast_ok(grad_value, grad_sampling_loc, grad_attn_weight, D, L, P))
         return backward_impl<float>(stream, grad_out, value, spatial_shapes, level_start, sampling_loc,
                                     attn_weight, N, S, M, D, L, Lq, P, grad_value, grad_sampling_loc,
@@ -379,8 +433,8 @@ static int check_fused(const void *value, const void *shapes, const void *starts
     SEMIDETR_REQUIRE(ref, SEMIDETR_E_BADARG, "msda_fused: null reference_points");
     SEMIDETR_REQUIRE(ref_dim == 2 || ref_dim == 4, SEMIDETR_E_BADARG,
                      "Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
-    SEMIDETR_REQUIRE(D == kD && L <= kMaxLevels && (int64_t)L * P <= 256, SEMIDETR_E_BADARG,
-                     "msda_fused: only channels == 32 (got %d), <= %d levels, L*P <= 256", D, kMaxLevels);
+    SEMIDETR_REQUIRE(D == kD && L <= kMaxLevels && (int64_t)L * P <= 256 && slice_ok(S, M), SEMIDETR_E_BADARG,
+                     "msda_fused: only channels == 32 (got %d), <= %d levels, L*P <= 256, image slice < 4 GB", D, kMaxLevels);
     SEMIDETR_REQUIRE((((uintptr_t)value | (uintptr_t)off) & 15) == 0, SEMIDETR_E_BADARG,
                      "msda_fused: value / sampling_offsets must be 16-byte aligned");
     return SEMIDETR_OK;

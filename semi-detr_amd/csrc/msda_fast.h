@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
         const int q = query_of(r);
-        int off[4] = {-1, -1, -1, -1};
+        unsigned off[4] = {kOob, kOob, kOob, kOob};      // out of range -> the hardware returns zeros
         float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q >= 0) {
             const int l = k / P;
@@ -213,12 +213,12 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
             float x, y, lw, lh;
             io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
             const float a = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
-            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+            if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 w = make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw));
             }
         }
-        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
         rec_w[r * LPP + k] = w;
     }
     __syncthreads();
@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
     const int r = g / SPLIT, part = g % SPLIT;
     const int q = query_of(r);
-    const float *vb = value + ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
+    // value slice of image n as a raw buffer: out-of-range offsets (invalid corners) read as zero
+    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
+    const unsigned lane_b = (unsigned)(t.m * kD + 4 * j) * 4u;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int4 *ro = rec_off + r * LPP;
     const float4 *rw = rec_w + r * LPP;
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     for (int k = part; k < LP; k += SPLIT) {
         const int4 o = ro[k];
         const float4 w = rw[k];
-        const float4 v1 = ld4(vb, o.x), v2 = ld4(vb, o.y), v3 = ld4(vb, o.z), v4 = ld4(vb, o.w);
+        const float4 v1 = buf_ld4(vr, (unsigned)o.x + lane_b), v2 = buf_ld4(vr, (unsigned)o.y + lane_b);
+        const float4 v3 = buf_ld4(vr, (unsigned)o.z + lane_b), v4 = buf_ld4(vr, (unsigned)o.w + lane_b);
         acc.x += w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
         acc.y += w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
         acc.z += w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
         const int q = t.q0 + r;
-        int off[4] = {-1, -1, -1, -1};
+        unsigned off[4] = {kOob, kOob, kOob, kOob};
         const int l = k / P;
         float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
         if (q < Lq) {
@@ -307,20 +310,20 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
             io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
             // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
             pr.z = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
-            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+            if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                 pr.x = lw;
                 pr.y = lh;
             }
         }
-        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
         rec_p[r * LPP + k] = pr;
     }
     __syncthreads();
 
     const int hw = threadIdx.x >> 5, c = threadIdx.x & 31;      // half-wave index, channel
-    const int64_t vo = ((int64_t)t.n * S * M + t.m) * kD + c;
-    const float *vb = value + vo;
-    float *gvb = gvalue + vo;
+    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
+    const unsigned lane_b = (unsigned)(t.m * kD + c) * 4u;
+    float *gvb = gvalue + (int64_t)t.n * S * M * kD + t.m * kD + c;      // + corner byte offset / 4
     for (int r = hw; r < RPB; r += 8) {
         const int q = t.q0 + r;
         if (q >= Lq) break;
@@ -336,18 +339,16 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
             const int l = __float_as_int(pr.w);
             const float hh = 1.f - lh, hwt = 1.f - lw;
             const float ga = go * a;
-            float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-            if (o.x >= 0) v1 = vb[o.x];
-            if (o.y >= 0) v2 = vb[o.y];
-            if (o.z >= 0) v3 = vb[o.z];
-            if (o.w >= 0) v4 = vb[o.w];
-            if (o.x >= 0) fp_atomic_add(gvb + o.x, hh * hwt * ga);
-            if (o.y >= 0) fp_atomic_add(gvb + o.y, hh * lw * ga);
-            if (o.z >= 0) fp_atomic_add(gvb + o.z, lh * hwt * ga);
-            if (o.w >= 0) fp_atomic_add(gvb + o.w, lh * lw * ga);
-            float pa = go * (hh * hwt * v1 + hh * lw * v2 + lh * hwt * v3 + lh * lw * v4);
-            float px = ga * (hh * (v2 - v1) + lh * (v4 - v3));
-            float py = ga * (hwt * (v3 - v1) + lw * (v4 - v2));
+            // d_i = grad_out[c] * v_i[c]; corners outside the level read as zero (buffer bounds check)
+            const float d1 = go * buf_ld1(vr, (unsigned)o.x + lane_b), d2 = go * buf_ld1(vr, (unsigned)o.y + lane_b);
+            const float d3 = go * buf_ld1(vr, (unsigned)o.z + lane_b), d4 = go * buf_ld1(vr, (unsigned)o.w + lane_b);
+            if ((unsigned)o.x != kOob) fp_atomic_add(gvb + ((unsigned)o.x >> 2), hh * hwt * ga);
+            if ((unsigned)o.y != kOob) fp_atomic_add(gvb + ((unsigned)o.y >> 2), hh * lw * ga);
+            if ((unsigned)o.z != kOob) fp_atomic_add(gvb + ((unsigned)o.z >> 2), lh * hwt * ga);
+            if ((unsigned)o.w != kOob) fp_atomic_add(gvb + ((unsigned)o.w >> 2), lh * lw * ga);
+            float pa = hh * hwt * d1 + hh * lw * d2 + lh * hwt * d3 + lh * lw * d4;
+            float px = a * (hh * (d2 - d1) + lh * (d4 - d3));
+            float py = a * (hwt * (d3 - d1) + lw * (d4 - d2));
             pa = half32_sum(pa);
             px = half32_sum(px);
             py = half32_sum(py);
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
         const int q = t.q0 + r;
-        int off[4] = {-1, -1, -1, -1};
+        unsigned off[4] = {kOob, kOob, kOob, kOob};
         const int l = k / P;
         float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
         if (q < Lq) {
@@ -403,25 +404,26 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
             io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
             // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
             pr.z = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
-            if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+            if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                 pr.x = lw;
                 pr.y = lh;
             }
         }
-        rec_off[r * LPP + k] = make_int4(off[0], off[1], off[2], off[3]);
+        rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
         rec_p[r * LPP + k] = pr;
     }
     __syncthreads();
 
     const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
     const int q = t.q0 + r;
-    const float *vb = value + ((int64_t)t.n * S * M + t.m) * kD + 4 * j;
+    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
+    const unsigned lane_b = (unsigned)(t.m * kD + 4 * j) * 4u;
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < Lq) go = *reinterpret_cast<const float4 *>(gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j);
     const int4 *ro = rec_off + r * LPP;
     float4 *rp = rec_p + r * LPP;
     // Batches of kGU samples, unrolled by hand: the result store into rec_p would otherwise keep the compiler
-    // from hoisting the next samples' record reads / corner loads above it (4 * kGU loads in flight per lane; measured on MI355X at the encoder shape: kGU 1 / 2 / 4 -> 438 / 508 / 643 us, so 1).
+    // from hoisting the next samples' record reads / corner loads above it (4 * kGU loads in flight per lane; measured on MI355X at the encoder shape, bs 4: kGU 1 / 2 / 4 -> 370 / 389 / 375 us, so 1).
     constexpr int kGU = 1;
     for (int k0 = 0; k0 < LP; k0 += kGU) {
         int4 o[kGU];
@@ -433,9 +435,11 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
             pr[u] = rp[k];
         }
 #pragma unroll
-        for (int u = 0; u < kGU; ++u) {
-            v[u][0] = ld4(vb, o[u].x); v[u][1] = ld4(vb, o[u].y);
-            v[u][2] = ld4(vb, o[u].z); v[u][3] = ld4(vb, o[u].w);
+        for (int u = 0; u < kGU; ++u) {      // corners outside the level read as zero (buffer bounds check)
+            v[u][0] = buf_ld4(vr, (unsigned)o[u].x + lane_b);
+            v[u][1] = buf_ld4(vr, (unsigned)o[u].y + lane_b);
+            v[u][2] = buf_ld4(vr, (unsigned)o[u].z + lane_b);
+            v[u][3] = buf_ld4(vr, (unsigned)o[u].w + lane_b);
         }
 #pragma unroll
         for (int u = 0; u < kGU; ++u) {
@@ -443,21 +447,12 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
             const float lw = pr[u].x, lh = pr[u].y, a = pr[u].z;
             const int l = __float_as_int(pr[u].w);
             const float hh = 1.f - lh, hw = 1.f - lw;
-            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-            const float4 v1 = v[u][0], v2 = v[u][1], v3 = v[u][2], v4 = v[u][3];
-            const float4 ga = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
-            float pa = go.x * (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) +
-                       go.y * (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) +
-                       go.z * (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) +
-                       go.w * (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w);
-            float px = ga.x * (hh * (v2.x - v1.x) + lh * (v4.x - v3.x)) +
-                       ga.y * (hh * (v2.y - v1.y) + lh * (v4.y - v3.y)) +
-                       ga.z * (hh * (v2.z - v1.z) + lh * (v4.z - v3.z)) +
-                       ga.w * (hh * (v2.w - v1.w) + lh * (v4.w - v3.w));
-            float py = ga.x * (hw * (v3.x - v1.x) + lw * (v4.x - v2.x)) +
-                       ga.y * (hw * (v3.y - v1.y) + lw * (v4.y - v2.y)) +
-                       ga.z * (hw * (v3.z - v1.z) + lw * (v4.z - v2.z)) +
-                       ga.w * (hw * (v3.w - v1.w) + lw * (v4.w - v2.w));
+            // d_i = <grad_out, v_i> over this lane's 4 channels
+            auto dot4 = [&](const float4 &vv) { return go.x * vv.x + go.y * vv.y + go.z * vv.z + go.w * vv.w; };
+            const float d1 = dot4(v[u][0]), d2 = dot4(v[u][1]), d3 = dot4(v[u][2]), d4 = dot4(v[u][3]);
+            float pa = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
+            float px = a * (hh * (d2 - d1) + lh * (d4 - d3));
+            float py = a * (hw * (d3 - d1) + lw * (d4 - d2));
             pa = group8_sum(pa);
             px = group8_sum(px);
             py = group8_sum(py);
