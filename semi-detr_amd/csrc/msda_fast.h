@@ -97,11 +97,6 @@ __device__ __forceinline__ float group8_sum(float x)
     return x;
 }
 
-__device__ __forceinline__ float4 ld4(const float *p, int off)
-{
-    return off >= 0 ? *reinterpret_cast<const float4 *>(p + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 // Softmax over the L*P logits of one (n, q, m) row (ms_deform_attn.py:101), evaluated cooperatively by the LP
 // consecutive threads that own the row's samples: one expf per sample, max / sum by xor-shuffles when LP is a
 // power of two <= 64 (the DINO case LP = 16 is one DPP row); any other LP falls back to a per-thread loop.
