@@ -503,7 +503,7 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
                                                  //        reads may run past a share's end, results unused);
                                                  // back : misses {weight, query << 25 | pixel index}
     __shared__ float gtile[kTQ * kD];            // grad_out rows of the patch
-    __shared__ int cnt[kWR], start[kWR];
+    __shared__ int cnt[kWR], start[kWR], rowoff[kWR];   // per window row: count, first entry, element offset
     __shared__ int stats2[2][4], wsum[kWinThreads / 64];   // stats double-buffered by level parity: a fast
                                                            // wavefront may start level l+1 while others still read l's
 
@@ -617,6 +617,10 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
                 const int excl = base + incl - v;
                 if (j0 < kWR) start[j0] = excl;
                 if (j0 + 1 < kWR) start[j0 + 1] = excl + c0;
+                // element offset of the window row's pixel inside the image slice (only used for touched rows, which
+                // are always pixels of the level)
+                if (j0 < kWR) rowoff[j0] = (st + (y0 + j0 / kWW) * W + x0 + j0 % kWW) * rs;
+                if (j0 + 1 < kWR) rowoff[j0 + 1] = (st + (y0 + (j0 + 1) / kWW) * W + x0 + (j0 + 1) % kWW) * rs;
                 if (tid == kWinThreads - 1) stats[3] = excl + v;            // total number of bucketed entries
             }
             __syncthreads();
@@ -624,7 +628,9 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
 #pragma unroll
             for (int cidx = 0; cidx < 4; ++cidx)
                 if (off[cidx] >= 0 && inw[cidx])
-                    entries[start[wrow[cidx]] + rank[cidx]] = make_float2(cw[cidx], __int_as_float((wrow[cidx] << 8) | i));
+                    entries[start[wrow[cidx]] + rank[cidx]] =        // bit 30: last entry of its row
+                        make_float2(cw[cidx], __int_as_float((rank[cidx] == cnt[wrow[cidx]] - 1 ? (1 << 30) : 0) |
+                                                             (wrow[cidx] << 8) | i));
             __syncthreads();
             // ---- owner computes: 32 streams of 16 lanes (lane l = channels l and l+16) each walk an equal share
             //      of the row-sorted entries, keep the running row sum in two registers and flush a finished row
@@ -637,25 +643,29 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
                 const int total = stats[3];
                 const int lo = (int)((int64_t)total * sid / kStreams);
                 const int hi = (int)((int64_t)total * (sid + 1) / kStreams);
-                int cur = -1;
+                // acc += w * grad_out[q]; an entry flagged "last of its row" flushes the row sum (the row's element
+                // offset comes from the rowoff table) and clears it.  A share that ends in the middle of a row
+                // flushes its partial sum at the end; one that starts in the middle simply starts from zero.
+                int cur = -1;           // row of the most recent entry whose sum is still open, or -1
                 float2 accv = make_float2(0.f, 0.f);
                 auto flush = [&](int rowi) {
-                    float *pr = gvs + (int64_t)(st + (y0 + rowi / kWW) * W + x0 + rowi % kWW) * rs;
+                    float *pr = gvs + rowoff[rowi];
                     fp_atomic_add(pr, accv.x);
                     fp_atomic_add(pr + 16, accv.y);
                 };
-                // software pipeline: 8 independent entry reads, then 8 independent grad_out reads, then the (short)
-                // dependent accumulate / row-change chain.  Full batches run without bounds checks.
                 auto step = [&](const float2 &en, const float2 &gq) {
-                    const int rowi = __float_as_int(en.y) >> 8;
-                    if (rowi != cur) {
-                        if (cur >= 0) flush(cur);
-                        cur = rowi;
-                        accv = make_float2(0.f, 0.f);
-                    }
+                    const int pk = __float_as_int(en.y);
                     accv.x += en.x * gq.x;
                     accv.y += en.x * gq.y;
+                    cur = (pk >> 8) & 0x3fffff;
+                    if (pk & (1 << 30)) {
+                        flush(cur);
+                        accv = make_float2(0.f, 0.f);
+                        cur = -1;
+                    }
                 };
+                // software pipeline: 8 independent entry reads, then 8 independent grad_out reads, then the short
+                // dependent chain.  Full batches run without bounds checks.
                 int e = lo;
                 for (; e + 8 <= hi; e += 8) {
                     float2 en[8], gq[8];
