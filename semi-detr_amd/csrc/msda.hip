@@ -337,15 +337,9 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
 {
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * kD, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    if ((Lq == S && P == kPT && S < (1 << 25) && g_bwd_variant == 0) || g_bwd_variant == 64) {
-        SEMIDETR_REQUIRE(Lq == S && P == kPT && S < (1 << 25), SEMIDETR_E_BADARG,
-                         "msda_backward: the windowed kernel needs num_query == spatial_size < 2^25 and num_point == 4");
-        // patches are enumerated on the device (the level table lives in device memory); a workgroup takes
-        // patches slot, slot + tiles_bound, ... so any bound >= 1 is correct; this one covers the usual
-        // pyramids (sum of ceil(H/8)*ceil(W/16) <= S/128 * 1.25 + 4 per level) in a single round.
-        const int tiles_bound = (S + kTQ - 1) / kTQ * 5 / 4 + 4 * L;
-        const int64_t grid = (int64_t)N * tiles_bound * M;
-        SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+    if ((Lq == S && P == kPT && S < (1 << 24) && g_bwd_variant == 0) || g_bwd_variant == 64 || g_bwd_variant == 65) {
+        SEMIDETR_REQUIRE(Lq == S && P == kPT && S < (1 << 24), SEMIDETR_E_BADARG,
+                         "msda_backward: the windowed kernel needs num_query == spatial_size < 2^24 and num_point == 4");
         {   // gather half: the two small gradients, streams like the forward
             const int gt = (Lq + 31) / 32;
             const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
@@ -353,8 +347,22 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
         }
-        hipLaunchKernelGGL(msda_bwd_scatter_d32_win<IO>, dim3((unsigned)grid), dim3(kWinThreads), 0, st, grad_out,
-                           spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
+        // patches are enumerated on the device (the level table lives in device memory); a workgroup takes
+        // patches slot, slot + tiles_bound, ... so any bound >= 1 is correct; this one covers the usual
+        // pyramids (about S / patch size, ragged edges included) in a single round.
+        // measured at the 800x1333 encoder shape, bs 4: 8x16 patches 687 us / 784 MB of row atomics, 16x16 patches
+        // 593 us / 604 MB (fewer halo rows per query); 64 forces the small patch
+        const bool big = g_bwd_variant != 64;
+        const int patch = big ? 256 : 128;
+        const int tiles_bound = (S + patch - 1) / patch * 5 / 4 + 4 * L;
+        const int64_t grid = (int64_t)N * tiles_bound * M;
+        SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+        if (big)
+            hipLaunchKernelGGL((msda_bwd_scatter_d32_win<IO, 16, 16, 32, 32>), dim3((unsigned)grid), dim3(kWinThreads),
+                               0, st, grad_out, spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
+        else
+            hipLaunchKernelGGL((msda_bwd_scatter_d32_win<IO, 8, 16, 24, 32>), dim3((unsigned)grid), dim3(kWinThreads),
+                               0, st, grad_out, spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
         return semidetr::launch_status("msda_bwd_scatter_d32_win");
     }
     // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles

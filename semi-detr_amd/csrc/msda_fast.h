@@ -486,22 +486,23 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
 //   * corners outside the window (rare in the encoder) are put on a miss list and scattered one full-line
 //     atomic each, exactly like the plain kernel -- any sampling pattern is correct, locality only decides speed.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTH = 8, kTW = 16, kTQ = kTH * kTW;       // query patch: 8 x 16 pixels = 128 queries
-constexpr int kWH = 24, kWW = 32, kWR = kWH * kWW;      // window: 24 x 32 value rows = 768 counters
-constexpr int kWinThreads = 512;                        // 8 wavefronts = 16 half-waves
-constexpr int kPT = 4;                                  // num_point (compile time: one sample per thread)
-constexpr int kNE = kTQ * kPT * 4;                      // corners per (patch, level)
+constexpr int kWinThreads = 512;                        // 8 wavefronts = 32 streams of 16 lanes
+constexpr int kPT = 4;                                  // num_point (compile time)
 
-template <typename IO = LocAttnIO>
+// TH x TW = query patch (pixels), WH x WW = value-row window per sampling level (both compile time).
+// Every thread owns SPT = TH*TW*4 / 512 (query, point) samples of the patch.
+template <typename IO, int TH, int TW, int WH, int WW>
 __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int tiles_bound, float *__restrict__ gvalue)
 {
-    static_assert(kTQ * kPT == kWinThreads, "one (query, point) sample per thread");
+    constexpr int kTQ = TH * TW, kWR = WH * WW, kNE = kTQ * kPT * 4, SPT = kTQ * kPT / kWinThreads;
+    static_assert(SPT * kWinThreads == kTQ * kPT && SPT >= 1, "whole samples per thread");
     static_assert(kWR <= 2 * kWinThreads, "scan assigns two counters per thread");
-    __shared__ float2 entries[kNE + 8];          // front: bucketed {weight, window row << 8 | query} (+8: batch
-                                                 //        reads may run past a share's end, results unused);
-                                                 // back : misses {weight, query << 25 | pixel index}
+    static_assert(kTQ <= 256 && kWR <= (1 << 14), "entry packing: 8 bits query, row above");
+    __shared__ float2 entries[kNE + 8];          // front: bucketed {weight, last << 30 | window row << 8 | query}
+                                                 //        (+8: batch reads may run past a share's end, unused);
+                                                 // back : misses {weight, query << 24 | pixel index}
     __shared__ float gtile[kTQ * kD];            // grad_out rows of the patch
     __shared__ int cnt[kWR], start[kWR], rowoff[kWR];   // per window row: count, first entry, element offset
     __shared__ int stats2[2][4], wsum[kWinThreads / 64];   // stats double-buffered by level parity: a fast
@@ -515,88 +516,101 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
     const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
 
     for (int tile = slot;; tile += tiles_bound) {
-        // ---- which patch of which level is tile number `tile`? (uniform across the workgroup)
-        int lq = -1, acc = 0, ntx = 1, Hq = 0, Wq = 0, stq = 0;
-        for (int l = 0; l < L; ++l) {
-            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-            const int nx = (W + kTW - 1) / kTW, nt = ((H + kTH - 1) / kTH) * nx;
-            if (tile < acc + nt) { lq = l; ntx = nx; Hq = H; Wq = W; stq = (int)starts[l]; break; }
-            acc += nt;
+        const Patch pt = find_patch<TH, TW>(tile, shapes, starts, L);
+        if (pt.Hq == 0) break;
+        // this thread's samples = (query i, point p) of the patch, sample index tid + sp * 512
+        int qs[SPT];
+        int64_t srow[SPT];
+        float sm_max[SPT], sm_inv[SPT];
+#pragma unroll
+        for (int sp = 0; sp < SPT; ++sp) {
+            const int sidx = tid + sp * kWinThreads, i = sidx / P, p = sidx - i * P;
+            qs[sp] = patch_query<TW>(pt, i);
+            srow[sp] = qs[sp] >= 0 ? ((int64_t)n * Lq + qs[sp]) * M + m : 0;
+            // fused prologue: softmax statistics of the (query, head) row, once per patch.  The row's L*P logits
+            // belong to the P threads of the query (a quad for P = 4), L each: quad reductions.
+            sm_max[sp] = 0.f;
+            sm_inv[sp] = 1.f;
+            if (IO::kSoftmax) {
+                float mx = -__builtin_huge_valf();
+                if (qs[sp] >= 0)
+                    for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow[sp], LP, l * P + p));
+                mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+                float sum = 0.f;
+                if (qs[sp] >= 0)
+                    for (int l = 0; l < L; ++l) sum += expf(io.load_w(srow[sp], LP, l * P + p) - mx);
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                sm_max[sp] = mx;
+                sm_inv[sp] = 1.f / sum;
+            }
         }
-        if (lq < 0) break;
-        const int ty = (tile - acc) / ntx, tx = (tile - acc) % ntx;
-        // this thread's sample = (query i, point p) of the patch
-        const int i = tid / P, p = tid - i * P;
-        const int qy = ty * kTH + i / kTW, qx = tx * kTW + i % kTW;
-        const int q = (qy < Hq && qx < Wq) ? stq + qy * Wq + qx : -1;
-        const int64_t srow = q >= 0 ? ((int64_t)n * Lq + q) * M + m : 0;
         // patch centre in normalised coordinates (pixel centres are (i + 0.5) / size)
-        const float pcy = (ty * kTH + 0.5f * kTH) / (float)Hq, pcx = (tx * kTW + 0.5f * kTW) / (float)Wq;
-        // fused prologue: softmax statistics of this thread's (query, head) row, once per patch.  The row's L*P
-        // logits belong to the P threads of the query (a quad for P = 4), L each: quad reductions.
-        float sm_max = 0.f, sm_inv = 1.f;
-        if (IO::kSoftmax) {
-            float mx = -__builtin_huge_valf();
-            if (q >= 0)
-                for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow, LP, l * P + p));
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-            float sum = 0.f;
-            if (q >= 0)
-                for (int l = 0; l < L; ++l) sum += expf(io.load_w(srow, LP, l * P + p) - mx);
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            sm_max = mx;
-            sm_inv = 1.f / sum;
-        }
+        const float pcy = (pt.y0 + 0.5f * TH) / (float)pt.Hq, pcx = (pt.x0 + 0.5f * TW) / (float)pt.Wq;
         __syncthreads();                      // previous patch fully done before its LDS state is reused
         for (int r = hw; r < kTQ; r += kWinThreads / 32) {      // stage grad_out of the patch, channels (c, c+16)
-            const int ry = ty * kTH + r / kTW, rx = tx * kTW + r % kTW;   // interleaved: lane l of a 16-lane stream
+            const int rq = patch_query<TW>(pt, r);                        // interleaved: lane l of a 16-lane stream
             gtile[r * kD + (c & 15) * 2 + (c >> 4)] =                     // reads both with one ds_read_b64
-                (ry < Hq && rx < Wq) ? gout[(((int64_t)n * Lq + stq + ry * Wq + rx) * M + m) * kD + c] : 0.f;
+                rq >= 0 ? gout[(((int64_t)n * Lq + rq) * M + m) * kD + c] : 0.f;
         }
         for (int l = 0; l < L; ++l) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
             // window: where the patch centre maps to on this level, minus half the window
-            const int y0 = (int)floorf(pcy * H - 0.5f) - kWH / 2 + 1;
-            const int x0 = (int)floorf(pcx * W - 0.5f) - kWW / 2 + 1;
+            const int y0 = (int)floorf(pcy * H - 0.5f) - WH / 2 + 1;
+            const int x0 = (int)floorf(pcx * W - 0.5f) - WW / 2 + 1;
             int *stats = stats2[l & 1];
             if (tid < 4) stats[tid] = 0;
             for (int k = tid; k < kWR; k += kWinThreads) cnt[k] = 0;
-            // ---- this thread's sample geometry
-            int off[4] = {-1, -1, -1, -1};
-            float lw = 0.f, lh = 0.f, a = 0.f;
-            int h0 = 0, w0 = 0;
-            if (q >= 0) {
-                const int k = l * P + p;
-                float x, y;
-                io.load_xy(srow, (int64_t)n * Lq + q, LP, k, l, P, H, W, x, y);
-                if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
-                    a = io.load_w(srow, LP, k);
-                    if (IO::kSoftmax) a = expf(a - sm_max) * sm_inv;
-                    // the top-left corner (h0, w0) exactly as sample_setup derived it
-                    h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
-                    w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
+            // ---- this thread's sample geometry: per corner weight, window row (or -1: miss, -2: no corner)
+            float cw[SPT][4];
+            int wrow[SPT][4], rank[SPT][4], pix[SPT][4];
+#pragma unroll
+            for (int sp = 0; sp < SPT; ++sp) {
+                const int sidx = tid + sp * kWinThreads, p = sidx % P;
+                int off[4] = {-1, -1, -1, -1};
+                float lw = 0.f, lh = 0.f, a = 0.f;
+                int h0 = 0, w0 = 0;
+                if (qs[sp] >= 0) {
+                    const int k = l * P + p;
+                    float x, y;
+                    io.load_xy(srow[sp], (int64_t)n * Lq + qs[sp], LP, k, l, P, H, W, x, y);
+                    if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+                        a = io.load_w(srow[sp], LP, k);
+                        if (IO::kSoftmax) a = expf(a - sm_max[sp]) * sm_inv[sp];
+                        // the top-left corner (h0, w0) exactly as sample_setup derived it
+                        h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
+                        w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
+                    }
+                }
+                const int wy = h0 - y0, wx = w0 - x0;
+                const bool in_y0 = (unsigned)wy < (unsigned)WH, in_y1 = (unsigned)(wy + 1) < (unsigned)WH;
+                const bool in_x0 = (unsigned)wx < (unsigned)WW, in_x1 = (unsigned)(wx + 1) < (unsigned)WW;
+                const int wi = wy * WW + wx;
+                const float hh = 1.f - lh, hwt = 1.f - lw;
+                const float cwv[4] = {hh * hwt * a, hh * lw * a, lh * hwt * a, lh * lw * a};
+                const bool inw[4] = {in_y0 && in_x0, in_y0 && in_x1, in_y1 && in_x0, in_y1 && in_x1};
+                const int wr[4] = {wi, wi + 1, wi + WW, wi + WW + 1};
+#pragma unroll
+                for (int cidx = 0; cidx < 4; ++cidx) {
+                    cw[sp][cidx] = cwv[cidx];
+                    wrow[sp][cidx] = off[cidx] < 0 ? -2 : (inw[cidx] ? wr[cidx] : -1);
+                    pix[sp][cidx] = off[cidx] / rs;      // pixel index inside the image (misses only)
+                    rank[sp][cidx] = 0;
                 }
             }
             __syncthreads();                  // counters zeroed, previous level's walk finished
             // ---- bucket the in-window corners by window row (count), list the others as misses
-            const int wy = h0 - y0, wx = w0 - x0;
-            const bool in_y0 = (unsigned)wy < (unsigned)kWH, in_y1 = (unsigned)(wy + 1) < (unsigned)kWH;
-            const bool in_x0 = (unsigned)wx < (unsigned)kWW, in_x1 = (unsigned)(wx + 1) < (unsigned)kWW;
-            const int wi = wy * kWW + wx;
-            const float hh = 1.f - lh, hwt = 1.f - lw;
-            const float cw[4] = {hh * hwt * a, hh * lw * a, lh * hwt * a, lh * lw * a};
-            const bool inw[4] = {in_y0 && in_x0, in_y0 && in_x1, in_y1 && in_x0, in_y1 && in_x1};
-            const int wrow[4] = {wi, wi + 1, wi + kWW, wi + kWW + 1};
-            int rank[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
-                if (off[cidx] < 0) continue;
-                if (inw[cidx]) rank[cidx] = atomicAdd(&cnt[wrow[cidx]], 1);
-                else   // off = pixel index * rs: keep the pixel index (< 2^25, checked by the launcher) + the query
-                    entries[kNE - 1 - atomicAdd(&stats[1], 1)] =
-                        make_float2(cw[cidx], __int_as_float((int)(((unsigned)i << 25) | (unsigned)(off[cidx] / rs))));
+            for (int sp = 0; sp < SPT; ++sp) {
+                const int i = (tid + sp * kWinThreads) / P;
+#pragma unroll
+                for (int cidx = 0; cidx < 4; ++cidx) {
+                    if (wrow[sp][cidx] >= 0) rank[sp][cidx] = atomicAdd(&cnt[wrow[sp][cidx]], 1);
+                    else if (wrow[sp][cidx] == -1)   // keep the pixel index (< 2^24, checked by the launcher) + query
+                        entries[kNE - 1 - atomicAdd(&stats[1], 1)] = make_float2(
+                            cw[sp][cidx], __int_as_float((int)(((unsigned)i << 24) | (unsigned)pix[sp][cidx])));
+                }
             }
             __syncthreads();
             // ---- exclusive scan of the kWR counters -> start[]  (thread t owns counters 2t, 2t+1)
@@ -619,18 +633,23 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
                 if (j0 + 1 < kWR) start[j0 + 1] = excl + c0;
                 // element offset of the window row's pixel inside the image slice (only used for touched rows, which
                 // are always pixels of the level)
-                if (j0 < kWR) rowoff[j0] = (st + (y0 + j0 / kWW) * W + x0 + j0 % kWW) * rs;
-                if (j0 + 1 < kWR) rowoff[j0 + 1] = (st + (y0 + (j0 + 1) / kWW) * W + x0 + (j0 + 1) % kWW) * rs;
+                if (j0 < kWR) rowoff[j0] = (st + (y0 + j0 / WW) * W + x0 + j0 % WW) * rs;
+                if (j0 + 1 < kWR) rowoff[j0 + 1] = (st + (y0 + (j0 + 1) / WW) * W + x0 + (j0 + 1) % WW) * rs;
                 if (tid == kWinThreads - 1) stats[3] = excl + v;            // total number of bucketed entries
             }
             __syncthreads();
-            // ---- fill the buckets
+            // ---- fill the buckets; bit 30 marks the last entry of its row
 #pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx)
-                if (off[cidx] >= 0 && inw[cidx])
-                    entries[start[wrow[cidx]] + rank[cidx]] =        // bit 30: last entry of its row
-                        make_float2(cw[cidx], __int_as_float((rank[cidx] == cnt[wrow[cidx]] - 1 ? (1 << 30) : 0) |
-                                                             (wrow[cidx] << 8) | i));
+            for (int sp = 0; sp < SPT; ++sp) {
+                const int i = (tid + sp * kWinThreads) / P;
+#pragma unroll
+                for (int cidx = 0; cidx < 4; ++cidx) {
+                    const int wr = wrow[sp][cidx];
+                    if (wr >= 0)
+                        entries[start[wr] + rank[sp][cidx]] = make_float2(
+                            cw[sp][cidx], __int_as_float((rank[sp][cidx] == cnt[wr] - 1 ? (1 << 30) : 0) | (wr << 8) | i));
+                }
+            }
             __syncthreads();
             // ---- owner computes: 32 streams of 16 lanes (lane l = channels l and l+16) each walk an equal share
             //      of the row-sorted entries, keep the running row sum in two registers and flush a finished row
@@ -692,8 +711,8 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
                 for (int mi = sid; mi < nmiss; mi += kStreams) {
                     const float2 en = entries[kNE - 1 - mi];
                     const int pk = __float_as_int(en.y);
-                    const float2 g2 = gt2[((unsigned)pk >> 25) * 16 + l16];
-                    float *pr = gvs + (int64_t)(pk & 0x1ffffff) * rs;
+                    const float2 g2 = gt2[((unsigned)pk >> 24) * 16 + l16];
+                    float *pr = gvs + (int64_t)(pk & 0xffffff) * rs;
                     fp_atomic_add(pr, en.x * g2.x);
                     fp_atomic_add(pr + 16, en.x * g2.y);
                 }
@@ -701,4 +720,3 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
         }
     }
 }
-
