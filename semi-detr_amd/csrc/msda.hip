@@ -37,10 +37,21 @@ constexpr int kMaxLevels = 32;
 // ---------------------------------------------------------------------------------------------
 // sample geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 corner validity)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+// Individually rounded multiply / subtract.  HIP's __fmul_rn / __fsub_rn are plain operators that hipcc's default
+// -ffp-contract=fast fuses into one fma(y, H, -0.5); the pixel coordinate (hence floor(), the bilinear cell)
+// must round exactly like the oracle's two C operations, so contraction is switched off for these four.
+template <typename T>
+__device__ __forceinline__ T mul_rn(T a, T b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+template <typename T>
+__device__ __forceinline__ T sub_rn(T a, T b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
 
 // off[i] = element offset of corner i relative to (value + n*S*M*D + m*D), or -1 when the corner is
 // outside the level (zero padding).  Returns false when the whole sample is skipped.
