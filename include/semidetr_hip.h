@@ -13,6 +13,7 @@
 #ifndef SEMIDETR_HIP_H
 #define SEMIDETR_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -24,7 +25,7 @@ extern "C" {
 #define SEMIDETR_E_TOOLARGE (-2)    /* an index would overflow the 32-bit arithmetic used on device  */
 #define SEMIDETR_E_NODEVICE (-3)    /* no HIP device available                                        */
 
-#define SEMIDETR_ABI_VERSION 1
+#define SEMIDETR_ABI_VERSION 2
 
 int semidetr_abi_version(void);
 const char *semidetr_last_error(void);
@@ -202,15 +203,54 @@ int semidetr_ema_flat_f32(void *stream, float *teacher, const float *student, in
  * the batch.
  *
  * Replaces  the per-image loop in DinoDetrSSOD.extract_teacher_info  detr_ssod/models/dino_detr_ssod.py:918-939
- *   proposals (sumK, 5) fp32 x1,y1,x2,y2,score ; labels (sumK,) int64 ; prop_offsets (B+1,) int32 DEVICE
+ *   proposals (sumK, 5) fp32 x1,y1,x2,y2,score ; labels (sumK,) int64 ; prop_offsets (B+1,) int32 DEVICE:
+ *   image b's proposals are rows [prop_offsets[b], prop_offsets[b+1]); with prop_counts (B,) int32 DEVICE
+ *   (nullable) only the first prop_counts[b] of them exist -- the padded layout semidetr_pseudo_nms_f32 emits.
  *   out_boxes (sumK,4), out_labels (sumK,), out_scores (sumK,): image b's kept entries are written
  *   compacted, in the original order, starting at prop_offsets[b]; out_count (B,) int32 kept per image;
  *   out_thr (B,) fp32 the threshold used (NaN for <2 proposals, as torch.std gives).
  * ------------------------------------------------------------------------------------------- */
 int semidetr_pseudo_label_filter_f32(void *stream, const float *proposals, const int64_t *labels,
-                                     const int32_t *prop_offsets, int num_images, float *out_boxes,
+                                     const int32_t *prop_offsets, const int32_t *prop_counts,
+                                     int num_images, float *out_boxes,
                                      int64_t *out_labels, float *out_scores, int32_t *out_keep_idx,
                                      int32_t *out_count, float *out_thr);
+
+/* ---------------------------------------------------------------------------------------------
+ * Teacher test-time box decoding for pseudo labels, whole batch, no host
+ * round trip: sigmoid, cxcywh -> clamped pixel xyxy, score threshold, class-aware greedy NMS, the
+ * max_per_img best by score.
+ *
+ * Replaces  DINODETRSSODHead._get_bboxes_single(for_pseudo_label=True)
+ *               detr_od/models/dense_heads/dino_detr_ssod_head.py:1364-1395 (called per image from :1320-1331)
+ *           multiclass_nms  thirdparty/mmdetection/mmdet/core/post_processing/bbox_nms.py:8-95
+ *           mmcv.ops.batched_nms / nms (mmcv-full 1.3.16, un-vendored: README.md:11,30)
+ *   cls_logits (B,Q,C) fp32 raw logits of the last decoder layer; bbox_pred (B,Q,4) fp32 normalised cxcywh;
+ *   img_hw (B,2) fp32 DEVICE = img_meta['img_shape'][:2] (height, width); Q <= 2048; 1 <= max_per_img <= 2048.
+ *   workspace: semidetr_nms_workspace_bytes(B,Q,C) bytes of device memory, 16-byte aligned.
+ *   out_dets (B,max_per_img,5) x1,y1,x2,y2,score; out_labels (B,max_per_img) int64; out_count (B,) int32:
+ *   image b's detections are the first out_count[b] rows of its slice, by descending score (equal logits:
+ *   ascending query*C + class; the reference's order of exact ties is unspecified).
+ * ------------------------------------------------------------------------------------------- */
+size_t semidetr_nms_workspace_bytes(int batch, int num_query, int num_classes);
+int semidetr_pseudo_nms_f32(void *stream, const float *cls_logits, const float *bbox_pred, const float *img_hw,
+                            int batch, int num_query, int num_classes, float score_thr, float iou_thr,
+                            int max_per_img, void *workspace, size_t workspace_bytes, float *out_dets,
+                            int64_t *out_labels, int32_t *out_count);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weak -> strong augmentation warp of the pseudo boxes, one launch for the batch.
+ *
+ * Replaces  Transform2D.transform_bboxes  detr_ssod/models/utils/bbox_utils.py:167-192 (bbox2points :18-25,
+ *           points2bbox :28-41), called through DinoDetrSSOD._transform_bbox  detr_ssod/models/dino_detr_ssod.py:804-807
+ *   boxes: rows of box_stride (>= 4) floats, x1,y1,x2,y2 first; image b owns rows [box_offsets[b], +n_b) with
+ *   n_b = box_counts[b] if box_counts else box_offsets[b+1] - box_offsets[b] (both int32 DEVICE arrays);
+ *   max_boxes_per_image >= every n_b (grid sizing); matrices (B,3,3) row major fp32; out_hw (B,2) fp32 (h, w)
+ *   of the target image; out_boxes rows of 4 floats at the same row indices.
+ * ------------------------------------------------------------------------------------------- */
+int semidetr_transform_bboxes_f32(void *stream, const float *boxes, int box_stride, const int32_t *box_offsets,
+                                  const int32_t *box_counts, int num_images, int max_boxes_per_image,
+                                  const float *matrices, const float *out_hw, float *out_boxes);
 
 #ifdef __cplusplus
 }

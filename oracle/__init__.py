@@ -160,3 +160,32 @@ def pseudo_label_filter(proposal):
     thr = ctypes.c_float(0)
     n = lib().pseudo_label_oracle(_p(proposal), K, _p(keep), ctypes.byref(thr))
     return keep[:n].copy(), np.float32(thr.value)
+
+
+def pseudo_nms(cls_logits, bbox_pred, img_h, img_w, score_thr=0.01, iou_thr=0.6, max_num=300):
+    """One image: cls_logits (Q,C), bbox_pred (Q,4) -> (dets (k,5) float32, labels (k,) int64).
+    nms_oracle.c:pseudo_nms_oracle (head.py:1364-1395 + bbox_nms.py:8-95 + mmcv batched_nms restated)."""
+    cls_logits = _c(cls_logits, np.float32)
+    bbox_pred = _c(bbox_pred, np.float32)
+    Q, C = cls_logits.shape
+    cap = max(Q * C, 1) if max_num <= 0 else max_num
+    dets = np.zeros((cap, 5), np.float32)
+    labels = np.zeros(cap, np.int64)
+    fn = lib().pseudo_nms_oracle
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                   ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    n = fn(_p(cls_logits), _p(bbox_pred), Q, C, float(img_h), float(img_w), float(score_thr), float(iou_thr),
+           int(max_num), _p(dets), _p(labels))
+    return dets[:n].copy(), labels[:n].copy()
+
+
+def transform_bboxes(boxes, M, out_h, out_w):
+    """boxes (K,4), M (3,3) -> (K,4); nms_oracle.c:transform_bboxes_oracle (bbox_utils.py:167-192)."""
+    boxes = _c(boxes, np.float32).reshape(-1, 4)
+    M = _c(M, np.float32).reshape(9)
+    out = np.zeros_like(boxes)
+    fn = lib().transform_bboxes_oracle
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
+    fn.restype = None
+    fn(_p(boxes), boxes.shape[0], _p(M), float(out_h), float(out_w), _p(out))
+    return out

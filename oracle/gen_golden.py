@@ -13,6 +13,10 @@ What is imported from the reference (by file path, with stub registries for the 
   * thirdparty/mmdetection/mmdet/core/bbox/match_costs/match_cost.py (FocalLossCost, BBoxL1Cost, IoUCost)
   * thirdparty/mmdetection/mmdet/core/bbox/iou_calculators/iou2d_calculator.py (bbox_overlaps)
   * thirdparty/mmdetection/mmdet/core/bbox/transforms.py (cxcywh<->xyxy)
+  * thirdparty/mmdetection/mmdet/core/post_processing/bbox_nms.py (multiclass_nms) over a torch restatement of
+    the un-vendored mmcv-full 1.3.16 batched_nms / nms (the surrounding arithmetic is the reference's own, the
+    greedy suppression is the published algorithm: PARITY UNPINNED for the keep decisions)
+  * detr_ssod/models/utils/bbox_utils.py (Transform2D.transform_bboxes)
 The assignment itself comes from scipy.optimize.linear_sum_assignment (scipy 1.15.3), exactly as
 hungarian_assigner.py:136 calls it.  MeanTeacher / pseudo-label code needs mmcv to import, so those
 fixtures restate mean_teacher.py:46-64 and dino_detr_ssod.py:918-939 with the same torch calls.
@@ -335,6 +339,123 @@ def gen_pseudo():
     np.savez_compressed(os.path.join(OUT, "pseudo.npz"), **d)
 
 
+def _stub_nms(boxes, scores, iou_threshold):
+    """mmcv.ops.nms (1.3.16), offset 0, restated with torch ops: visit by descending score (stable), drop a box
+    when an earlier KEPT box overlaps it by more than the threshold (devIoU: inter / (Sa + Sb - inter))."""
+    order = torch.sort(scores, descending=True, stable=True)[1]
+    b = boxes[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    sup = torch.zeros(len(order), dtype=torch.bool)
+    keep = []
+    for i in range(len(order)):
+        if sup[i]:
+            continue
+        keep.append(i)
+        w = (torch.minimum(b[i, 2], b[i + 1:, 2]) - torch.maximum(b[i, 0], b[i + 1:, 0])).clamp(min=0)
+        h = (torch.minimum(b[i, 3], b[i + 1:, 3]) - torch.maximum(b[i, 1], b[i + 1:, 1])).clamp(min=0)
+        inter = w * h
+        sup[i + 1:] |= inter / (area[i] + area[i + 1:] - inter) > iou_threshold
+    keep = order[torch.tensor(keep, dtype=torch.long)]
+    return torch.cat([boxes[keep], scores[keep, None]], -1), keep
+
+
+def _stub_batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
+    """mmcv.ops.batched_nms (1.3.16) restated; split_thr = -1 (the reference's cfg, head.py:1375) selects the
+    per-class branch."""
+    cfg = dict(nms_cfg)
+    assert cfg.pop("type", "nms") == "nms" and not cfg.pop("class_agnostic", class_agnostic)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    boxes_for_nms = boxes + offsets[:, None]
+    split_thr = cfg.pop("split_thr", 10000)
+    assert not boxes_for_nms.shape[0] < split_thr
+    total_mask = scores.new_zeros(scores.size(), dtype=torch.bool)
+    scores_after_nms = scores.new_zeros(scores.size())
+    for id_ in torch.unique(idxs):
+        mask = (idxs == id_).nonzero(as_tuple=False).view(-1)
+        dets, keep = _stub_nms(boxes_for_nms[mask], scores[mask], cfg["iou_threshold"])
+        total_mask[mask[keep]] = True
+        scores_after_nms[mask[keep]] = dets[:, -1]
+    keep = total_mask.nonzero(as_tuple=False).view(-1)
+    scores, inds = scores_after_nms[keep].sort(descending=True, stable=True)
+    keep = keep[inds]
+    return torch.cat([boxes[keep], scores[:, None]], -1), keep
+
+
+def gen_nms(tr):
+    """_get_bboxes_single(for_pseudo_label=True) (head.py:1364-1395) restated line by line around the reference's
+    own multiclass_nms; logits are multiples of 1/64 so that equal scores <=> equal logits (tie order defined)."""
+    ops = types.ModuleType("mmcv.ops")
+    nms_mod = types.ModuleType("mmcv.ops.nms")
+    nms_mod.batched_nms = _stub_batched_nms
+    for n, m in (("mmcv", types.ModuleType("mmcv")), ("mmcv.ops", ops), ("mmcv.ops.nms", nms_mod)):
+        sys.modules[n] = m
+    pp = _load("ref_bbox_nms", REF + "/thirdparty/mmdetection/mmdet/core/post_processing/bbox_nms.py")
+    d, names = {}, []
+    g = torch.Generator().manual_seed(29)
+    cases = [("dino", 300, 80, (800, 1333), -5.0, 300), ("dense", 120, 20, (640, 480), 0.0, 300),
+             ("few", 64, 5, (333, 500), -6.5, 300), ("none", 40, 7, (100, 100), -12.0, 300),
+             ("topk", 200, 10, (512, 512), 1.0, 50), ("one", 1, 1, (64, 64), 2.0, 300)]
+    for name, Q, C, (ih, iw), bias, max_per_img in cases:
+        logits = torch.round((torch.randn(Q, C, generator=g) * 2.0 + bias) * 64) / 64
+        cxcy = torch.rand(Q, 2, generator=g)
+        k = max(Q // 6, 1)                              # clusters of near-duplicates so that NMS has work to do
+        cxcy[k:] = cxcy[torch.randint(0, k, (Q - k,), generator=g)] + torch.randn(Q - k, 2, generator=g) * 0.01
+        wh = torch.rand(Q, 2, generator=g) * 0.3 + 0.02
+        wh[k:] = wh[torch.randint(0, k, (Q - k,), generator=g)] * (1 + torch.randn(Q - k, 2, generator=g) * 0.05)
+        bbox_pred = torch.cat([cxcy, wh], -1)
+        # ---- head.py:1371-1395
+        cls_score = logits.sigmoid()
+        nms = dict(type='nms', iou_threshold=0.6, split_thr=-1)
+        score_thr = 0.01
+        padding = cls_score.new_zeros(cls_score.shape[0], 1)
+        cls_score = torch.cat([cls_score, padding], dim=1)
+        bp = tr.bbox_cxcywh_to_xyxy(bbox_pred)
+        bp[:, 0::2] = bp[:, 0::2] * iw
+        bp[:, 1::2] = bp[:, 1::2] * ih
+        bp[:, 0::2].clamp_(min=0, max=iw)
+        bp[:, 1::2].clamp_(min=0, max=ih)
+        det_bboxes, det_labels = pp.multiclass_nms(bp, cls_score, score_thr, nms, max_per_img)
+        names.append(name)
+        d[f"{name}.logits"], d[f"{name}.bbox_pred"] = logits.numpy(), bbox_pred.numpy()
+        d[f"{name}.img_hw"] = np.asarray([ih, iw], np.float32)
+        d[f"{name}.max_per_img"] = np.int64(max_per_img)
+        d[f"{name}.dets"] = det_bboxes.numpy().reshape(-1, 5)
+        d[f"{name}.labels"] = det_labels.numpy().astype(np.int64)
+    d["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(OUT, "nms.npz"), **d)
+
+
+def gen_transform():
+    """Transform2D.transform_bboxes (bbox_utils.py:167-192), imported by path (BitmapMasks stubbed)."""
+    for n in ["mmdet.core.mask", "mmdet.core.mask.structures"]:
+        if n not in sys.modules:
+            m = types.ModuleType(n)
+            m.__path__ = []
+            sys.modules[n] = m
+    sys.modules["mmdet.core.mask.structures"].BitmapMasks = type("BitmapMasks", (), {})
+    bu = _load("ref_bbox_utils", REF + "/detr_ssod/models/utils/bbox_utils.py")
+    d, names = {}, []
+    g = torch.Generator().manual_seed(31)
+    for k, K in enumerate((37, 1, 0, 300)):
+        xy = torch.rand(K, 2, generator=g) * torch.tensor([1200.0, 700.0])
+        wh = torch.rand(K, 2, generator=g) * 300 + 1
+        box = torch.cat([xy, xy + wh, torch.rand(K, 1, generator=g)], -1)
+        # a weak->strong matrix like the pipelines produce: scale, flip, translation, small shear (+ mild projective row)
+        s = 0.5 + torch.rand(1, generator=g).item()
+        M = torch.tensor([[-s if k % 2 else s, 0.07 * k, 30.0 * k + (1300.0 * s if k % 2 else 0.0)],
+                          [0.03 * k, s * 0.9, -12.0 * k], [0.0, 1e-5 * k, 1.0]])
+        out_shape = (600 + 50 * k, 900 + 30 * k, 3)
+        res = bu.Transform2D.transform_bboxes(box, M, out_shape)
+        n = f"t{k}_K{K}"
+        names.append(n)
+        d[f"{n}.boxes"], d[f"{n}.M"] = box.numpy(), M.numpy()
+        d[f"{n}.out_shape"] = np.asarray(out_shape[:2], np.float32)
+        d[f"{n}.out"] = res.numpy()
+    d["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(OUT, "transform.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     func, modl, mc, tr, _ = import_reference()
@@ -344,6 +465,8 @@ def main():
     gen_lsap()
     gen_ema()
     gen_pseudo()
+    gen_nms(tr)
+    gen_transform()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -39,7 +39,11 @@ SIGNATURES = {
     "semidetr_build_targets": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int64] + [c_void_p] * 5),
     "semidetr_ema_multi_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_double]),
     "semidetr_ema_flat_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_double]),
-    "semidetr_pseudo_label_filter_f32": (c_int, [c_void_p] * 4 + [c_int] + [c_void_p] * 6),
+    "semidetr_pseudo_label_filter_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 6),
+    "semidetr_nms_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "semidetr_pseudo_nms_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_void_p,
+                                                                       ctypes.c_size_t] + [c_void_p] * 3),
+    "semidetr_transform_bboxes_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 3),
 }
 
 _lib = None

@@ -23,13 +23,13 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 
 __global__ __launch_bounds__(256) void pseudo_label_kernel(
     const float *__restrict__ prop, const int64_t *__restrict__ labels, const int32_t *__restrict__ offs,
-    float *__restrict__ out_boxes, int64_t *__restrict__ out_labels, float *__restrict__ out_scores,
+    const int32_t *__restrict__ counts, float *__restrict__ out_boxes, int64_t *__restrict__ out_labels, float *__restrict__ out_scores,
     int32_t *__restrict__ out_keep, int32_t *__restrict__ out_count, float *__restrict__ out_thr)
 {
     __shared__ double red[4];
     __shared__ int wave_cnt[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int p0 = offs[b], K = offs[b + 1] - p0;
+    const int p0 = offs[b], K = counts ? counts[b] : offs[b + 1] - p0;
     const float *pb = prop + (int64_t)p0 * 5;
     if (K <= 0) {
         if (tid == 0) { out_count[b] = 0; out_thr[b] = __builtin_nanf(""); }
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(
 }  // namespace
 
 extern "C" int semidetr_pseudo_label_filter_f32(void *stream, const float *proposals, const int64_t *labels,
-                                                const int32_t *prop_offsets, int num_images,
-                                                float *out_boxes, int64_t *out_labels, float *out_scores,
+                                                const int32_t *prop_offsets, const int32_t *prop_counts,
+                                                int num_images, float *out_boxes, int64_t *out_labels, float *out_scores,
                                                 int32_t *out_keep_idx, int32_t *out_count, float *out_thr)
 {
     SEMIDETR_REQUIRE(num_images >= 0, SEMIDETR_E_BADARG, "pseudo_label: negative num_images");
@@ -89,7 +89,7 @@ extern "C" int semidetr_pseudo_label_filter_f32(void *stream, const float *propo
     SEMIDETR_REQUIRE(prop_offsets && out_count && out_thr, SEMIDETR_E_BADARG, "pseudo_label: null pointer argument");
     SEMIDETR_REQUIRE(!out_labels || labels, SEMIDETR_E_BADARG, "pseudo_label: out_labels without labels");
     hipLaunchKernelGGL(pseudo_label_kernel, dim3(num_images), dim3(256), 0, semidetr::as_stream(stream),
-                       proposals, labels, prop_offsets, out_boxes, out_labels, out_scores, out_keep_idx,
+                       proposals, labels, prop_offsets, prop_counts, out_boxes, out_labels, out_scores, out_keep_idx,
                        out_count, out_thr);
     return semidetr::launch_status("pseudo_label_kernel");
 }

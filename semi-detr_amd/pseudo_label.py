@@ -1,9 +1,14 @@
-"""Teacher pseudo-label filter on the MI355X (``csrc/pseudo_label.hip``).
+"""Teacher pseudo-label step on the MI355X (``csrc/pseudo_label.hip``, ``csrc/nms.hip``).
 
-Replaces the per-image Python loop of ``DinoDetrSSOD.extract_teacher_info``
-(detr_ssod/models/dino_detr_ssod.py:918-939): threshold = mean + unbiased std of the image's scores, keep
-``score >= thr``, drop boxes with non-positive width/height, keep post-NMS order.  One launch and one
-host read-back of the kept counts for the whole batch (the reference syncs several times per image).
+* ``filter_pseudo_labels`` replaces the per-image Python loop of ``DinoDetrSSOD.extract_teacher_info``
+  (detr_ssod/models/dino_detr_ssod.py:918-939): threshold = mean + unbiased std of the image's scores, keep
+  ``score >= thr``, drop boxes with non-positive width/height, keep post-NMS order.  One launch and one
+  host read-back of the kept counts for the whole batch (the reference syncs several times per image).
+* ``get_bboxes_for_pseudo_label`` replaces ``DINODETRSSODHead.get_bboxes(..., for_pseudo_label=True)`` /
+  ``_get_bboxes_single`` (detr_od/models/dense_heads/dino_detr_ssod_head.py:1320-1331, :1364-1395): sigmoid,
+  box decoding, ``multiclass_nms`` (mmdet bbox_nms.py:8-95 over mmcv.ops.batched_nms), top ``max_per_img``.
+* ``teacher_pseudo_labels`` chains both on the device: one host sync for the whole batch.
+* ``transform_bboxes`` replaces ``Transform2D.transform_bboxes`` (detr_ssod/models/utils/bbox_utils.py:167-192).
 """
 import ctypes
 
@@ -41,7 +46,7 @@ def filter_pseudo_labels(proposal_box_list, proposal_label_list, return_threshol
     out_thr = torch.empty(B, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().semidetr_pseudo_label_filter_f32(
-            _lib.current_stream_ptr(), _p(prop), _p(lab), _p(offs_dev), B, _p(out_boxes), _p(out_labels),
+            _lib.current_stream_ptr(), _p(prop), _p(lab), _p(offs_dev), _p(None), B, _p(out_boxes), _p(out_labels),
             _p(out_scores), _p(out_keep), _p(out_count), _p(out_thr))
     _lib.check(rc, "semidetr_pseudo_label_filter_f32")
     kept = out_count.tolist()          # the one host sync: list lengths are data dependent
@@ -51,3 +56,113 @@ def filter_pseudo_labels(proposal_box_list, proposal_label_list, return_threshol
     if return_threshold:
         return det_bboxes, det_labels, det_scores, out_thr
     return det_bboxes, det_labels, det_scores
+
+
+def _img_hw(img_metas, dev):
+    return _lib_small([[float(m["img_shape"][0]), float(m["img_shape"][1])] for m in img_metas], torch.float32, dev)
+
+
+def _lib_small(values, dtype, dev):
+    """Small host list -> device tensor through pinned memory (no stream sync)."""
+    t = torch.tensor(values, dtype=dtype)
+    return t.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else t.to(dev)
+
+
+def _nms_batch(cls_scores, bbox_preds, img_metas, score_thr, iou_threshold, max_per_img):
+    if cls_scores.device.type != "cuda":
+        raise RuntimeError("get_bboxes_for_pseudo_label: tensors must live on the GPU (no CPU fallback)")
+    if cls_scores.dim() != 3 or bbox_preds.shape != cls_scores.shape[:2] + (4,):
+        raise ValueError(f"expected cls_scores (B,Q,C) and bbox_preds (B,Q,4), got {tuple(cls_scores.shape)} "
+                         f"and {tuple(bbox_preds.shape)}")
+    B, Q, C = cls_scores.shape
+    assert len(img_metas) == B
+    dev = cls_scores.device
+    logits = cls_scores.detach().to(torch.float32).contiguous()
+    boxes = bbox_preds.detach().to(torch.float32).contiguous()
+    hw = _img_hw(img_metas, dev)
+    lib = _lib.lib()
+    ws = torch.empty(max(int(lib.semidetr_nms_workspace_bytes(B, Q, C)), 16), dtype=torch.uint8, device=dev)
+    dets = torch.empty((B, max_per_img, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_per_img), dtype=torch.int64, device=dev)
+    count = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.semidetr_pseudo_nms_f32(_lib.current_stream_ptr(), _p(logits), _p(boxes), _p(hw), B, Q, C,
+                                         float(score_thr), float(iou_threshold), int(max_per_img), _p(ws),
+                                         ws.numel(), _p(dets), _p(labels), _p(count))
+    _lib.check(rc, "semidetr_pseudo_nms_f32")
+    return dets, labels, count
+
+
+def get_bboxes_for_pseudo_label(cls_scores, bbox_preds, img_metas, score_thr=0.01, iou_threshold=0.6,
+                                max_per_img=300):
+    """cls_scores (B,Q,C) raw logits and bbox_preds (B,Q,4) normalised cxcywh of the LAST decoder layer
+    (``all_cls_scores[-1]``, ``all_bbox_preds[-1]``); img_metas: dicts with 'img_shape'.
+    Returns the reference's result_list: [(det_bboxes (k,5), det_labels (k,)), ...]."""
+    dets, labels, count = _nms_batch(cls_scores, bbox_preds, img_metas, score_thr, iou_threshold, max_per_img)
+    kept = count.tolist()              # the one host sync: list lengths are data dependent
+    return [(dets[b, :kept[b]], labels[b, :kept[b]]) for b in range(len(kept))]
+
+
+def teacher_pseudo_labels(cls_scores, bbox_preds, img_metas, score_thr=0.01, iou_threshold=0.6, max_per_img=300,
+                          return_proposals=False):
+    """extract_teacher_info's box path end to end on the device (dino_detr_ssod.py:904-939): decoding + NMS, then
+    the mean+std filter, chained through device-side counts.  Returns (det_bboxes, det_labels, det_scores)."""
+    dets, labels, count = _nms_batch(cls_scores, bbox_preds, img_metas, score_thr, iou_threshold, max_per_img)
+    B, dev = dets.shape[0], dets.device
+    offs = _lib_small([b * max_per_img for b in range(B + 1)], torch.int32, dev)
+    out_boxes = torch.empty((B * max_per_img, 4), dtype=torch.float32, device=dev)
+    out_labels = torch.empty(B * max_per_img, dtype=torch.int64, device=dev)
+    out_scores = torch.empty(B * max_per_img, dtype=torch.float32, device=dev)
+    out_count = torch.empty(B, dtype=torch.int32, device=dev)
+    out_thr = torch.empty(B, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().semidetr_pseudo_label_filter_f32(
+            _lib.current_stream_ptr(), _p(dets), _p(labels), _p(offs), _p(count), B, _p(out_boxes), _p(out_labels),
+            _p(out_scores), _p(None), _p(out_count), _p(out_thr))
+    _lib.check(rc, "semidetr_pseudo_label_filter_f32")
+    both = torch.stack([count, out_count]).tolist()       # the one host sync
+    res = ([out_boxes[b * max_per_img:b * max_per_img + both[1][b]] for b in range(B)],
+           [out_labels[b * max_per_img:b * max_per_img + both[1][b]] for b in range(B)],
+           [out_scores[b * max_per_img:b * max_per_img + both[1][b]] for b in range(B)])
+    if return_proposals:
+        return res + ([(dets[b, :both[0][b]], labels[b, :both[0][b]]) for b in range(B)],)
+    return res
+
+
+def transform_bboxes(bbox, M, out_shape):
+    """Transform2D.transform_bboxes for a list of (K_i, 4|5) boxes, (3,3) matrices and (h, w[, c]) shapes (or a
+    single triple).  A 5th column (score) is passed through."""
+    single = isinstance(bbox, torch.Tensor)
+    boxes = [bbox] if single else list(bbox)
+    mats = [M] if single else list(M)
+    shapes = [out_shape] if single else list(out_shape)
+    assert len(boxes) == len(mats) == len(shapes)
+    B = len(boxes)
+    if B == 0:
+        return []
+    dev = boxes[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("transform_bboxes: tensors must live on the GPU (no CPU fallback)")
+    counts = [int(b.shape[0]) for b in boxes]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    total = offs[-1]
+    out_list = [b for b in boxes]
+    if total:
+        cat = torch.cat([b[:, :4].to(torch.float32) for b in boxes]).contiguous()
+        mt = torch.stack([m.to(device=dev, dtype=torch.float32).reshape(3, 3) for m in mats]).contiguous()
+        hw = _lib_small([[float(s[0]), float(s[1])] for s in shapes], torch.float32, dev)
+        offs_dev = _lib_small(offs, torch.int32, dev)
+        out = torch.empty((total, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().semidetr_transform_bboxes_f32(_lib.current_stream_ptr(), _p(cat), 4, _p(offs_dev), _p(None),
+                                                          B, max(counts), _p(mt), _p(hw), _p(out))
+        _lib.check(rc, "semidetr_transform_bboxes_f32")
+        out_list = []
+        for b in range(B):
+            o = out[offs[b]:offs[b + 1]].to(boxes[b].dtype)
+            if counts[b] and boxes[b].shape[1] > 4:
+                o = torch.cat([o, boxes[b][:, 4:]], dim=1)
+            out_list.append(o if counts[b] else boxes[b])        # empty input is returned as is (bbox_utils.py:177-178)
+    return out_list[0] if single else out_list

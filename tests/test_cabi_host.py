@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/semidetr_hip.h but not exported"
     assert sorted(semi_detr_amd._lib.SIGNATURES) == names
-    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 1
+    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 2
 
 
 def test_host_side_argument_errors_need_no_gpu():
