@@ -11,7 +11,8 @@ SURVEY.md section 3.1), on synthetic inputs already resident in HBM:
     EMA teacher update (47 M fp32 params, ~500 tensors)                              [mean_teacher.py:37-64]
     60 MSDA forward launches  (6 enc + 6 dec layers x {sup bs1, teacher bs4, student-nograd bs4,
                                student forward_dummy bs4, teacher forward_dummy bs4})
-    pseudo-label filter (4 images x 300 proposals)                                    [dino_detr_ssod.py:918-939]
+    teacher pseudo labels: box decoding + class-aware NMS (4 x 900 x 80) + mean/std filter + weak->strong box warp
+                                                        [dino_detr_ssod_head.py:1364-1395, dino_detr_ssod.py:918-939]
     39 Hungarian matchings in 3 batched calls (4 inline unsup + 7x1 sup + 7x4 unsup)  [hungarian_assigner.py]
     24 MSDA backward launches (sup bs1 + student forward_dummy bs4, 6 enc + 6 dec each)
     N > 1: mean all-reduce of the 60 M-float gradient arena over RCCL/xGMI, bucketed, overlapped with backward
@@ -141,9 +142,16 @@ class Workload:
             return bp, cp, gts * layers, labs * layers, metas * layers
 
         self.match_sets = [problems(4, 1), problems(1, 7), problems(4, 7)]
-        self.proposals = [torch.cat([rand(300, 2) * 800, rand(300, 2) * 300 + 810, rand(300, 1) ** 3], -1)
-                          for _ in range(4)]
-        self.prop_labels = [torch.randint(0, 80, (300,), generator=g, device=dev) for _ in range(4)]
+        # teacher outputs of the 4 unlabeled images (last decoder layer): mostly background, clustered boxes
+        self.t_logits = (randn(4, NUM_QUERY, 80) * 2.0 - 5.0).contiguous()
+        k = NUM_QUERY // 8
+        cxcy, wh = rand(4, NUM_QUERY, 2), rand(4, NUM_QUERY, 2) * 0.3 + 0.02
+        src = torch.randint(0, k, (NUM_QUERY - k,), generator=g, device=dev)
+        cxcy[:, k:] = cxcy[:, src] + randn(4, NUM_QUERY - k, 2) * 0.01
+        wh[:, k:] = wh[:, src] * (1 + randn(4, NUM_QUERY - k, 2) * 0.05)
+        self.t_boxes = torch.cat([cxcy, wh], -1).contiguous()
+        self.t_metas = [dict(img_shape=(800, 1333, 3))] * 4
+        self.warp = [torch.tensor([[-0.9, 0.0, 1200.0], [0.0, 0.9, 12.0], [0.0, 0.0, 1.0]], device=dev)] * 4
         sizes = dino_param_sizes()
         self.n_params = sum(sizes)
         self.teacher = [randn(n) for n in sizes]
@@ -183,6 +191,10 @@ class Workload:
                 MSDA.ms_deform_attn_backward(v, self.shapes, self.starts, loc, a, go, 64)
         self._timed(f"msda_bwd_{kind}_bs{n}_Lq{lq}", reps, msda_alg_bytes(n, lq, True), run)
 
+    def _pseudo(self):
+        boxes, labels, scores = self.sda.teacher_pseudo_labels(self.t_logits, self.t_boxes, self.t_metas)
+        self.sda.transform_bboxes(boxes, self.warp, [m["img_shape"] for m in self.t_metas])
+
     def _match(self, i):
         bp, cp, gts, labs, metas = self.match_sets[i]
         self._timed("hungarian_batch", 1, 0,
@@ -197,7 +209,7 @@ class Workload:
         q, qd = NUM_QUERY, NUM_QUERY + DN_PAD
         self._fwd("enc", 1, S, 6); self._fwd("dec", 1, qd, 6)            # supervised student forward
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, q, 6)             # teacher simple_test
-        self._timed("pseudo_label", 1, 0, lambda: sda.filter_pseudo_labels(self.proposals, self.prop_labels))
+        self._timed("pseudo_label", 1, 0, self._pseudo)
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, q, 6)             # student no-grad forward
         self._match(0)                                                   # inline matching, unsup_loss
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, qd, 6)            # student forward_dummy
@@ -422,7 +434,7 @@ def main():
             "config": {"workload": "Semi-DETR COCO-10%% teacher-student step, hot path only, per GPU 1 labeled + 4 "
                                    "unlabeled 800x1333 images: 60 MSDA fwd + 24 MSDA bwd launches (S=22223, M=8, "
                                    "D=32, L=4, P=4, Lq=22223/900/1100), 39 Hungarian problems (Q=900, G~U[1,15]), "
-                                   "EMA over %d params, pseudo-label filter; dense GEMMs/backbone not included"
+                                   "EMA over %d params, teacher NMS + pseudo-label filter + box warp; dense GEMMs/backbone not included"
                                    % wl.n_params,
                        "images_per_gpu": IMAGES_PER_GPU,
                        "parallelism": "dp%d image-sharded, grad all-reduce %d fp32 over RCCL" % (world, GRAD_ELEMS)

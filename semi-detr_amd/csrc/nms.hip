@@ -15,11 +15,12 @@
 // ascending flat index q * C + c -- a 64-bit key {orderable(logit), ~flat}; all keys are distinct, so the
 // result is deterministic although the final list is assembled with atomics.
 //
-// Three launches:
-//   nms_prepare_kernel (grid B):      boxes of the image, boxes.max() over the thresholded candidates
-//   nms_class_kernel   (grid C x B):  one workgroup per (class, image): bitonic sort of the class's candidates in
-//                                     LDS, greedy suppression in sorted order, survivors appended to the image's list
-//   nms_topk_kernel    (grid B):      radix select of the max_per_img largest keys (when more survive), sort, emit
+// Three launches (after one memset of the per-image scalars):
+//   nms_prepare_kernel (grid Q/4 x B): one wavefront per query: its box, boxes.max() over the thresholded candidates
+//   nms_class_kernel   (grid C x B):   ONE wavefront per (class, image): bitonic sort of the class's candidates in
+//                                      LDS, greedy suppression in sorted order, survivors appended to the image's list
+//   nms_topk_kernel    (grid B):       radix select of the max_per_img largest keys (when more than 2048 survive;
+//                                      bank-spread per-lane histograms, stops as soon as the rest fits), sort, emit
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -45,11 +46,14 @@ __device__ __forceinline__ float4 decode_box(const float *bp, float img_h, float
                        fminf(fmaxf(y2, 0.f), img_h));
 }
 
+// thr >= 0 (checked by the launcher): disjoint boxes have inter == 0, i.e. a ratio of 0 or NaN -- never above thr,
+// so the division is only evaluated for intersecting pairs (same decisions as the plain formula).
 __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr)
 {
     const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
     const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
-    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float width = right - left, height = bottom - top;
+    if (!(width > 0.f && height > 0.f)) return false;
     const float inter = width * height;
     const float sa = (a.z - a.x) * (a.w - a.y), sb = (b.z - b.x) * (b.w - b.y);
     return inter / (sa + sb - inter) > thr;
@@ -82,30 +86,35 @@ inline Workspace carve(void *ws, int B, int Q, int C)
     return w;
 }
 
-// ---- boxes of the image + boxes.max() over the queries that have at least one class above the threshold
+// ---- boxes of the image + boxes.max() over the queries that have at least one class above the threshold.
+// One wavefront per query (lanes stride the classes), 16 queries per workgroup; boxes are clamped to [0, size],
+// so the running maximum is an integer atomic max on the float's bits, one per workgroup (the slot is zeroed by
+// the launcher together with count).
+constexpr int kPrepQueries = 16;
 __global__ __launch_bounds__(256) void nms_prepare_kernel(const float *__restrict__ logits,
                                                           const float *__restrict__ bbox_pred,
                                                           const float *__restrict__ img_hw, int Q, int C,
                                                           float score_thr, Workspace ws)
 {
     __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float img_h = img_hw[2 * b], img_w = img_hw[2 * b + 1];
-    float mx = -__builtin_huge_valf();
-    for (int q = tid; q < Q; q += 256) {
+    float mx = 0.f;
+    for (int r = wv; r < kPrepQueries; r += 4) {
+        const int q = blockIdx.x * kPrepQueries + r;
+        if (q >= Q) break;
         const float4 box = decode_box(bbox_pred + ((size_t)b * Q + q) * 4, img_h, img_w);
-        ws.boxes[(size_t)b * Q + q] = box;
         const float *lr = logits + ((size_t)b * Q + q) * C;
         bool any = false;
-        for (int c = 0; c < C; ++c) any |= sigmoidf_(lr[c]) > score_thr;
-        if (any) mx = fmaxf(mx, fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w)));
+        for (int c = lane; c < C; c += 64) any |= sigmoidf_(lr[c]) > score_thr;
+        if (lane == 0) ws.boxes[(size_t)b * Q + q] = box;
+        if (__ballot(any) != 0ull) mx = fmaxf(mx, fmaxf(fmaxf(box.x, box.y), fmaxf(box.z, box.w)));
     }
-    for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    if (lane == 0) red[wv] = mx;
     __syncthreads();
-    if (tid == 0) {
-        ws.maxc[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        ws.count[b] = 0;
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (mx > 0.f) atomicMax(reinterpret_cast<int *>(ws.maxc) + b, __float_as_int(mx));   // >= 0: int order == float order
     }
 }
 
@@ -128,20 +137,26 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long *keys, int n2)
     __syncthreads();
 }
 
-// ---- one (class, image): sort the class's candidates, greedy NMS, append the survivors to the image's list
+// ---- one (class, image): sort the class's candidates, greedy NMS, append the survivors to the image's list.
+// ONE wavefront per problem; the C x B problems spread over the CUs.  The greedy scan runs in chunks of 64 sorted
+// candidates (lane = candidate): each lane first checks its box against the boxes kept so far (uniform LDS reads),
+// then builds the bit row of earlier chunk members it overlaps; the chunk is resolved in order with scalar bit
+// operations.  Exactly the sequential algorithm's decisions, but ~n/64 dependent steps instead of n.
+constexpr int kClsThreads = 64;
 template <int NP2>
-__global__ __launch_bounds__(256) void nms_class_kernel(const float *__restrict__ logits, int Q, int C,
-                                                        float score_thr, float iou_thr, Workspace ws)
+__global__ __launch_bounds__(kClsThreads) void nms_class_kernel(const float *__restrict__ logits, int Q, int C,
+                                                                float score_thr, float iou_thr, Workspace ws)
 {
     __shared__ unsigned long long keys[NP2];
-    __shared__ float4 ob[NP2];
-    __shared__ unsigned char sup[NP2];
-    __shared__ int s_n, s_base, wave_cnt[4];
+    __shared__ float4 ob[NP2];       // class-offset boxes in score order
+    __shared__ float4 kb[NP2];       // ... of the candidates kept so far
+    __shared__ int s_n, s_base;
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (tid == 0) s_n = 0;
     __syncthreads();
     int mine = 0;
-    for (int q = tid; q < NP2; q += 256) {
+#pragma unroll 8
+    for (int q = tid; q < NP2; q += kClsThreads) {
         unsigned long long key = 0;
         if (q < Q) {
             const float x = logits[((size_t)b * Q + q) * C + c];
@@ -153,97 +168,133 @@ __global__ __launch_bounds__(256) void nms_class_kernel(const float *__restrict_
         keys[q] = key;
     }
     if (mine) atomicAdd(&s_n, mine);
-    bitonic_desc<256>(keys, NP2);
+    bitonic_desc<kClsThreads>(keys, NP2);
     const int n = s_n;
     if (n == 0) return;
     const float off = (float)c * (ws.maxc[b] + 1.0f);
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += kClsThreads) {
         const int q = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
         const float4 bx = ws.boxes[(size_t)b * Q + q];
         ob[i] = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
-        sup[i] = 0;
     }
     __syncthreads();
-    for (int i = 0; i < n; ++i) {
-        if (sup[i]) continue;                       // uniform: every thread reads the same flag
-        const float4 bi = ob[i];
-        for (int j = i + 1 + tid; j < n; j += 256)
-            if (!sup[j] && iou_gt(bi, ob[j], iou_thr)) sup[j] = 1;
-        __syncthreads();
-    }
-    // survivors -> the image's list, flat index q * C + c in the key
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + tid;
-        const bool keep = i < n && !sup[i];
-        const unsigned long long mask = __ballot(keep);
-        const int lane = tid & 63, wv = tid >> 6;
-        __syncthreads();
-        if (lane == 0) wave_cnt[wv] = __popcll(mask);
-        __syncthreads();
-        const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        if (tid == 0) s_base = total ? atomicAdd(&ws.count[b], total) : 0;
-        __syncthreads();
-        int wbase = 0;
-        for (int w = 0; w < wv; ++w) wbase += wave_cnt[w];
-        if (keep) {
-            const unsigned q = 0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull);
-            const unsigned flat = q * (unsigned)C + (unsigned)c;
-            ws.keys[(size_t)b * Q * C + s_base + wbase + __popcll(mask & ((1ull << lane) - 1ull))] =
-                (keys[i] & 0xFFFFFFFF00000000ull) | (unsigned)(0xFFFFFFFFu - flat);
+    int m = 0;                                   // kept so far (uniform)
+    const unsigned long long lt = (1ull << tid) - 1ull;
+    for (int i0 = 0; i0 < n; i0 += kClsThreads) {
+        const int j = i0 + tid;
+        const bool valid = j < n;
+        const float4 bj = ob[valid ? j : 0];
+        // (both loops are chains of uniform LDS reads: unrolled so that eight reads are in flight, no short circuit)
+        bool hit = false;
+        int k = 0;
+        for (; k + 8 <= m; k += 8) {
+            float4 kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kk[u] = kb[k + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hit |= iou_gt(kk[u], bj, iou_thr);
         }
-        base += total;
+        for (; k < m; ++k) hit |= iou_gt(kb[k], bj, iou_thr);
+        const bool alive = valid && !hit;
+        unsigned long long row = 0;              // earlier members of this chunk that would suppress me
+        const int cn = n - i0 < kClsThreads ? n - i0 : kClsThreads;
+        int i = 0;
+        for (; i + 8 <= cn; i += 8) {
+            float4 kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kk[u] = ob[i0 + i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + u < tid && iou_gt(kk[u], bj, iou_thr)) row |= 1ull << (i + u);
+        }
+        for (; i < cn; ++i)
+            if (i < tid && iou_gt(ob[i0 + i], bj, iou_thr)) row |= 1ull << i;
+        // resolve the chunk in score order: member i is kept iff alive and no KEPT earlier member suppresses it
+        unsigned long long cand = __ballot(alive), kept = 0;
+        const unsigned row_lo = (unsigned)row, row_hi = (unsigned)(row >> 32);
+        while (cand) {
+            const int ci = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const unsigned long long ri = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)row_hi, ci) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)row_lo, ci);
+            if ((ri & kept) == 0) kept |= 1ull << ci;
+        }
+        const bool keep = (kept >> tid) & 1ull;
+        const int total = __popcll(kept);
+        if (keep) kb[m + __popcll(kept & lt)] = bj;
+        if (tid == 0) s_base = total ? atomicAdd(&ws.count[b], total) : 0;
+        __syncthreads();                         // kb and s_base visible
+        if (keep) {
+            const unsigned q = 0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull);
+            const unsigned flat = q * (unsigned)C + (unsigned)c;
+            ws.keys[(size_t)b * Q * C + s_base + __popcll(kept & lt)] =
+                (keys[j] & 0xFFFFFFFF00000000ull) | (unsigned)(0xFFFFFFFFu - flat);
+        }
+        m += total;
+        __syncthreads();                         // s_base is rewritten by the next chunk
     }
-    (void)base;
 }
 
 // ---- per image: the max_num largest keys, sorted; decode and emit
 constexpr int kTopThreads = 1024, kTopCap = 2048;
+constexpr int kHistCopies = 64, kHistStride = 257;      // one histogram per lane id; the odd stride spreads a digit's
+                                                        // 64 copies over the 64 LDS banks (no same-address atomics)
 
 __global__ __launch_bounds__(kTopThreads) void nms_topk_kernel(const float *__restrict__ logits, int Q, int C,
                                                                int max_num, Workspace ws, float *__restrict__ dets,
                                                                int64_t *__restrict__ labels, int32_t *__restrict__ out_count)
 {
     __shared__ unsigned long long sel[kTopCap];
-    __shared__ int hist[256];
-    __shared__ int s_digit, s_remaining, s_fill;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int hist[kHistCopies * kHistStride];
+    __shared__ int bins[256];
+    __shared__ int s_digit, s_remaining, s_matching, s_fill;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int K = ws.count[b];
     const unsigned long long *keys = ws.keys + (size_t)b * Q * C;
     const int nout = K < max_num ? K : max_num;
     for (int i = tid; i < kTopCap; i += kTopThreads) sel[i] = 0;
-    if (tid == 0) s_fill = 0;
+    if (tid == 0) { s_fill = 0; s_remaining = nout; s_matching = K; }
     __syncthreads();
     if (K <= kTopCap) {
         for (int i = tid; i < K; i += kTopThreads) sel[i] = keys[i];
     } else {
-        // radix select, most significant byte first: after the last pass `prefix` IS the nout-th largest key
+        // Radix select, most significant byte first.  `prefix`/`mask` describe the keys still tied with the
+        // nout-th largest one; taken = nout - remaining keys are known to be above them.  As soon as everything
+        // not yet excluded fits the sort buffer the passes stop.
         unsigned long long prefix = 0, mask = 0;
-        if (tid == 0) s_remaining = nout;
         for (int pass = 7; pass >= 0; --pass) {
-            if (tid < 256) hist[tid] = 0;
+            for (int i = tid; i < kHistCopies * kHistStride; i += kTopThreads) hist[i] = 0;
             __syncthreads();
             for (int i = tid; i < K; i += kTopThreads) {
                 const unsigned long long k = keys[i];
-                if ((k & mask) == prefix) atomicAdd(&hist[(int)((k >> (8 * pass)) & 255)], 1);
+                if ((k & mask) == prefix) atomicAdd(&hist[lane * kHistStride + (int)((k >> (8 * pass)) & 255)], 1);
+            }
+            __syncthreads();
+            if (tid < 256) {
+                int v = 0;
+                for (int cp = 0; cp < kHistCopies; ++cp) v += hist[cp * kHistStride + tid];
+                bins[tid] = v;
             }
             __syncthreads();
             if (tid == 0) {
                 int rem = s_remaining, d = 255;
                 for (; d > 0; --d) {
-                    if (hist[d] >= rem) break;
-                    rem -= hist[d];
+                    if (bins[d] >= rem) break;
+                    rem -= bins[d];
                 }
                 s_digit = d;
                 s_remaining = rem;
+                s_matching = bins[d];
             }
             __syncthreads();
             prefix |= (unsigned long long)s_digit << (8 * pass);
             mask |= 0xFFull << (8 * pass);
+            if ((nout - s_remaining) + s_matching <= kTopCap) break;        // uniform
         }
+        // everything above the tied group plus the tied group itself (<= kTopCap keys; exactly nout after 8 passes)
         for (int i = tid; i < K; i += kTopThreads) {
             const unsigned long long k = keys[i];
-            if (k >= prefix) sel[atomicAdd(&s_fill, 1)] = k;       // exactly nout keys (all keys are distinct)
+            if ((k & mask) >= prefix) sel[atomicAdd(&s_fill, 1)] = k;
         }
     }
     bitonic_desc<kTopThreads>(sel, kTopCap);
@@ -320,20 +371,26 @@ extern "C" int semidetr_pseudo_nms_f32(void *stream, const float *cls_logits, co
                      "pseudo_nms: max_per_img must be in [1, %d] (got %d)", kTopCap, max_per_img);
     SEMIDETR_REQUIRE(cls_logits && bbox_pred && img_hw && out_dets && out_labels && workspace, SEMIDETR_E_BADARG,
                      "pseudo_nms: null pointer argument");
+    SEMIDETR_REQUIRE(iou_thr >= 0.f, SEMIDETR_E_BADARG, "pseudo_nms: iou_thr must be >= 0 (got %g)", (double)iou_thr);
     SEMIDETR_REQUIRE(Q <= 2048, SEMIDETR_E_TOOLARGE, "pseudo_nms: at most 2048 queries per image (got %d)", Q);
     SEMIDETR_REQUIRE((int64_t)Q * C < (int64_t)0xFFFFFFFF, SEMIDETR_E_TOOLARGE, "pseudo_nms: Q * C too large");
     SEMIDETR_REQUIRE(workspace_bytes_ >= workspace_bytes(B, Q, C), SEMIDETR_E_BADARG,
                      "pseudo_nms: workspace too small (%zu < %zu bytes)", workspace_bytes_, workspace_bytes(B, Q, C));
     SEMIDETR_REQUIRE(((uintptr_t)workspace & 15) == 0, SEMIDETR_E_BADARG, "pseudo_nms: workspace must be 16-byte aligned");
     const Workspace ws = carve(workspace, B, Q, C);
-    hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(256), 0, st, cls_logits, bbox_pred, img_hw, Q, C, score_thr, ws);
+    {   // maxc and count are adjacent 256-byte-aligned slots: one memset zeroes both (0 bits == 0.0f)
+        hipError_t e = hipMemsetAsync(ws.maxc, 0, align256(sizeof(float) * (size_t)B) + sizeof(int) * (size_t)B, st);
+        if (e != hipSuccess) return semidetr::fail((int)e, "pseudo_nms memset: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3((Q + kPrepQueries - 1) / kPrepQueries, B), dim3(256), 0, st, cls_logits, bbox_pred, img_hw, Q, C,
+                       score_thr, ws);
     if (int rc = semidetr::launch_status("nms_prepare_kernel")) return rc;
     if (Q <= 256)
-        hipLaunchKernelGGL(nms_class_kernel<256>, dim3(C, B), dim3(256), 0, st, cls_logits, Q, C, score_thr, iou_thr, ws);
+        hipLaunchKernelGGL(nms_class_kernel<256>, dim3(C, B), dim3(kClsThreads), 0, st, cls_logits, Q, C, score_thr, iou_thr, ws);
     else if (Q <= 1024)
-        hipLaunchKernelGGL(nms_class_kernel<1024>, dim3(C, B), dim3(256), 0, st, cls_logits, Q, C, score_thr, iou_thr, ws);
+        hipLaunchKernelGGL(nms_class_kernel<1024>, dim3(C, B), dim3(kClsThreads), 0, st, cls_logits, Q, C, score_thr, iou_thr, ws);
     else
-        hipLaunchKernelGGL(nms_class_kernel<2048>, dim3(C, B), dim3(256), 0, st, cls_logits, Q, C, score_thr, iou_thr, ws);
+        hipLaunchKernelGGL(nms_class_kernel<2048>, dim3(C, B), dim3(kClsThreads), 0, st, cls_logits, Q, C, score_thr, iou_thr, ws);
     if (int rc = semidetr::launch_status("nms_class_kernel")) return rc;
     hipLaunchKernelGGL(nms_topk_kernel, dim3(B), dim3(kTopThreads), 0, st, cls_logits, Q, C, max_per_img, ws, out_dets,
                        out_labels, out_count);
