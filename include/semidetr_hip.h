@@ -252,6 +252,31 @@ int semidetr_transform_bboxes_f32(void *stream, const float *boxes, int box_stri
                                   const int32_t *box_counts, int num_images, int max_boxes_per_image,
                                   const float *matrices, const float *out_hw, float *out_boxes);
 
+/* ---------------------------------------------------------------------------------------------
+ * One-to-many (task-aligned) assigner of the warm-up stage + its training targets (SURVEY.md section 8(f)
+ * row 4), all (layer, image) problems of a loss() call in one launch.
+ *
+ * Replaces  O2MAssigner.assign  detr_od/core/bbox/assigners/o2m_assigner.py:50-170 (teacher_assign=False, or
+ *           teacher_assign=True with multiple_pos=False via candidate_topk = 1)
+ *           the in_warm_up branch of DINODETRSSODHead._get_target_single
+ *               detr_od/models/dense_heads/dino_detr_ssod_head.py:1108-1165
+ * Batch layout as semidetr_match_cost_f32 (gt_offsets (B+1,) int32 DEVICE, img_wh (B,2) fp32 DEVICE = (w, h)),
+ * but cls_prob (B,Q,C) holds PROBABILITIES (the call site passes cls_score.sigmoid(), head.py:1111).
+ * max_gt_per_problem >= every G_b (<= 1024); Q <= 2048; candidate_topk <= Q unless total_gt == 0.
+ * Outputs, all (B,Q[,4]):
+ *   gt_inds int64 (0 background, g+1 positive), labels int64 (class of the gt or -1),
+ *   max_overlaps fp32 (IoU with the assigned gt; -1e8 when unassigned; 0 for a problem without gts),
+ *   assign_metrics fp32 (score^alpha * IoU^beta of the assigned pair, else 0),
+ *   labels_full int64 (class or num_classes), bbox_targets fp32 (gt as normalised cx,cy,w,h, else 0),
+ *   norm_metrics fp32 = metric / (max metric of the gt's positives + 10e-8) * max IoU of the gt's positives.
+ * ------------------------------------------------------------------------------------------- */
+int semidetr_o2m_assign_f32(void *stream, const float *bbox_pred, const float *cls_prob, const float *gt_bboxes,
+                            const int64_t *gt_labels, const int32_t *gt_offsets, const float *img_wh,
+                            int num_problems, int num_query, int num_classes, int total_gt,
+                            int max_gt_per_problem, int candidate_topk, float alpha, float beta,
+                            int64_t *gt_inds, int64_t *labels, float *max_overlaps, float *assign_metrics,
+                            int64_t *labels_full, float *bbox_targets, float *norm_metrics);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,3 +189,36 @@ def transform_bboxes(boxes, M, out_h, out_w):
     fn.restype = None
     fn(_p(boxes), boxes.shape[0], _p(M), float(out_h), float(out_w), _p(out))
     return out
+
+
+def o2m_assign(bbox_pred, cls_prob, gt_bboxes, gt_labels, img_w, img_h, topk=13, alpha=1.0, beta=6.0):
+    """One image -> (gt_inds int64, labels int64, max_overlaps f32, assign_metrics f32); o2m_oracle.c
+    (o2m_assigner.py:50-170)."""
+    bbox_pred, cls_prob = _c(bbox_pred, np.float32), _c(cls_prob, np.float32)
+    gt_bboxes, gt_labels = _c(gt_bboxes, np.float32).reshape(-1, 4), _c(gt_labels, np.int64)
+    Q, C, G = bbox_pred.shape[0], cls_prob.shape[1], gt_bboxes.shape[0]
+    gi, lab = np.zeros(max(Q, 1), np.int64), np.zeros(max(Q, 1), np.int64)
+    mo, am = np.zeros(max(Q, 1), np.float32), np.zeros(max(Q, 1), np.float32)
+    fn = lib().o2m_assign_oracle
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                                                ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 4
+    fn(_p(bbox_pred), _p(cls_prob), _p(gt_bboxes), _p(gt_labels), Q, C, G, float(img_w), float(img_h), int(topk),
+       float(alpha), float(beta), _p(gi), _p(lab), _p(mo), _p(am))
+    return gi[:Q], lab[:Q], mo[:Q], am[:Q]
+
+
+def o2m_targets(gt_inds, max_overlaps, assign_metrics, gt_bboxes, gt_labels, img_w, img_h, num_classes):
+    """-> (labels_full int64, bbox_targets (Q,4) f32, norm_metrics f32); o2m_oracle.c (head.py:1114-1165)."""
+    gt_inds, max_overlaps = _c(gt_inds, np.int64), _c(max_overlaps, np.float32)
+    assign_metrics = _c(assign_metrics, np.float32)
+    gt_bboxes, gt_labels = _c(gt_bboxes, np.float32).reshape(-1, 4), _c(gt_labels, np.int64)
+    Q, G = gt_inds.shape[0], gt_bboxes.shape[0]
+    lf, bt, nm = np.zeros(max(Q, 1), np.int64), np.zeros((max(Q, 1), 4), np.float32), np.zeros(max(Q, 1), np.float32)
+    fn = lib().o2m_targets_oracle
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int64] + \
+                  [ctypes.c_void_p] * 3
+    fn(_p(gt_inds), _p(max_overlaps), _p(assign_metrics), _p(gt_bboxes), _p(gt_labels), Q, G, float(img_w), float(img_h),
+       int(num_classes), _p(lf), _p(bt), _p(nm))
+    return lf[:Q], bt[:Q], nm[:Q]

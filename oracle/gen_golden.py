@@ -17,6 +17,7 @@ What is imported from the reference (by file path, with stub registries for the 
     the un-vendored mmcv-full 1.3.16 batched_nms / nms (the surrounding arithmetic is the reference's own, the
     greedy suppression is the published algorithm: PARITY UNPINNED for the keep decisions)
   * detr_ssod/models/utils/bbox_utils.py (Transform2D.transform_bboxes)
+  * detr_od/core/bbox/assigners/o2m_assigner.py (O2MAssigner) + o2m_assign_result.py
 The assignment itself comes from scipy.optimize.linear_sum_assignment (scipy 1.15.3), exactly as
 hungarian_assigner.py:136 calls it.  MeanTeacher / pseudo-label code needs mmcv to import, so those
 fixtures restate mean_teacher.py:46-64 and dino_detr_ssod.py:918-939 with the same torch calls.
@@ -456,6 +457,86 @@ def gen_transform():
     np.savez_compressed(os.path.join(OUT, "transform.npz"), **d)
 
 
+def gen_o2m(tr):
+    """The reference's own O2MAssigner (detr_od/core/bbox/assigners/o2m_assigner.py), imported by path, and the
+    warm-up branch of _get_target_single (dino_detr_ssod_head.py:1108-1165) restated with the same torch calls
+    (PseudoSampler: pos_inds = nonzero(gt_inds > 0), pos_assigned_gt_inds = gt_inds[pos_inds] - 1)."""
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda c: c
+
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        m.__path__ = getattr(m, "__path__", [])
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mod("mmdet.core.bbox.builder", BBOX_ASSIGNERS=_Reg())
+    mod("mmdet.core.bbox.match_costs", build_match_cost=lambda cfg: None)
+    mod("mmdet.core.bbox.assigners")
+    mod("mmdet.core.bbox.assigners.assign_result", AssignResult=object)
+    mod("mmdet.core.bbox.assigners.base_assigner", BaseAssigner=object)
+    mod("mmdet.utils")
+    mod("mmdet.utils.util_mixins", NiceRepr=object)
+    sys.modules["mmdet.utils"].util_mixins = sys.modules["mmdet.utils.util_mixins"]
+    mod("detr_ssod")
+    mod("detr_ssod.utils", log_every_n=lambda *a, **k: None, log_image_with_boxes=lambda *a, **k: None)
+    mod("refo2m")
+    _load("refo2m.o2m_assign_result", REF + "/detr_od/core/bbox/assigners/o2m_assign_result.py", "refo2m")
+    o2m = _load("refo2m.o2m_assigner", REF + "/detr_od/core/bbox/assigners/o2m_assigner.py", "refo2m")
+    assigner = o2m.O2MAssigner()
+    d, names = {}, []
+    g = torch.Generator().manual_seed(41)
+    cases = [("dino", 900, 80, 7, (800, 1333)), ("many_gt", 300, 80, 40, (640, 480)), ("one_gt", 100, 20, 1, (333, 500)),
+             ("few_q", 13, 5, 3, (200, 300)), ("no_gt", 50, 10, 0, (100, 100)), ("dup_gt", 200, 6, 6, (512, 512))]
+    for name, Q, C, G, (ih, iw) in cases:
+        xy = torch.rand(G, 2, generator=g) * torch.tensor([iw * 0.7, ih * 0.7])
+        wh = torch.rand(G, 2, generator=g) * torch.tensor([iw * 0.25, ih * 0.25]) + 8
+        gt = torch.cat([xy, xy + wh], -1)
+        gl = torch.randint(0, C, (G,), generator=g)
+        if name == "dup_gt":                     # overlapping ground truths: one query is a candidate of several
+            gt[3:] = gt[:3] + torch.rand(3, 4, generator=g) * 6
+        # predictions: most random, a third jittered copies of the ground truths so that IoUs are substantial
+        bp = torch.cat([torch.rand(Q, 2, generator=g), torch.rand(Q, 2, generator=g) * 0.3 + 0.02], -1)
+        if G:
+            src = torch.randint(0, G, (Q // 3,), generator=g)
+            f = torch.tensor([iw, ih, iw, ih], dtype=torch.float32)
+            near = tr.bbox_xyxy_to_cxcywh(gt[src] / f) * (1 + torch.randn(Q // 3, 4, generator=g) * 0.08)
+            bp[:Q // 3] = near.clamp(0.001, 0.999)
+        prob = torch.rand(Q, C, generator=g) ** 2
+        meta = dict(img_shape=(ih, iw, 3))
+        res = assigner.assign(bp, prob, gt, gl, meta)
+        # ---- head.py:1114-1160
+        INF = 100000000
+        assign_ious = res.max_overlaps.clone()
+        assign_ious[assign_ious == -INF] = 0
+        assign_metrics = res.assign_metrics
+        pos_inds = torch.nonzero(res.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        pos_assigned_gt_inds = res.gt_inds[pos_inds] - 1
+        labels = gt.new_full((Q,), C, dtype=torch.long)
+        bbox_targets = torch.zeros_like(bp)
+        factor = bp.new_tensor([iw, ih, iw, ih]).unsqueeze(0)
+        if G:
+            bbox_targets[pos_inds, :] = tr.bbox_xyxy_to_cxcywh(gt[pos_assigned_gt_inds] / factor)
+            labels[pos_inds] = gl[pos_assigned_gt_inds].long()
+        norm = assign_metrics.new_zeros(Q)
+        for gi in torch.unique(pos_assigned_gt_inds):
+            idx = pos_inds[pos_assigned_gt_inds == gi]
+            pm, pi = assign_metrics[idx], assign_ious[idx]
+            norm[idx] = pm / (pm.max() + 10e-8) * pi.max()
+        names.append(name)
+        for k, v in (("bbox_pred", bp), ("cls_prob", prob), ("gt_bboxes", gt.reshape(-1, 4)), ("gt_labels", gl),
+                     ("gt_inds", res.gt_inds), ("labels", res.labels), ("max_overlaps", res.max_overlaps),
+                     ("assign_metrics", res.assign_metrics), ("labels_full", labels), ("bbox_targets", bbox_targets),
+                     ("norm_metrics", norm)):
+            d[f"{name}.{k}"] = v.numpy()
+        d[f"{name}.img_hw"] = np.asarray([ih, iw], np.float32)
+    d["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(OUT, "o2m.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     func, modl, mc, tr, _ = import_reference()
@@ -467,6 +548,7 @@ def main():
     gen_pseudo()
     gen_nms(tr)
     gen_transform()
+    gen_o2m(tr)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

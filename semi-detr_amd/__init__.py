@@ -18,12 +18,12 @@ _sys.modules.setdefault("MultiScaleDeformableAttention", _msda_native)
 from .ops.functions import MSDeformAttnFunction, MSDeformAttnFusedFunction  # noqa: E402,F401
 from .ops.modules import MSDeformAttn  # noqa: E402,F401
 from .matcher import (AssignResult, BBoxL1Cost, FocalLossCost, HungarianAssigner, IoUCost,  # noqa: E402,F401
-                      linear_sum_assignment)
+                      O2MAssigner, O2MAssignResult, linear_sum_assignment)
 from .mean_teacher import MeanTeacher, ema_momentum, ema_update_, ema_update_flat_  # noqa: E402,F401
 from .pseudo_label import (filter_pseudo_labels, get_bboxes_for_pseudo_label, teacher_pseudo_labels,  # noqa: E402,F401
                            transform_bboxes)
 
 __all__ = ["MSDeformAttnFunction", "MSDeformAttnFusedFunction", "MSDeformAttn", "HungarianAssigner", "FocalLossCost", "BBoxL1Cost",
-           "IoUCost", "AssignResult", "linear_sum_assignment", "MeanTeacher", "ema_momentum", "ema_update_",
+           "IoUCost", "AssignResult", "O2MAssigner", "O2MAssignResult", "linear_sum_assignment", "MeanTeacher", "ema_momentum", "ema_update_",
            "ema_update_flat_", "filter_pseudo_labels", "get_bboxes_for_pseudo_label", "teacher_pseudo_labels",
            "transform_bboxes"]

@@ -6,6 +6,8 @@ Mirrors, name for name and argument for argument:
   * ``FocalLossCost`` / ``BBoxL1Cost`` / ``IoUCost``   .../match_costs/match_cost.py:8-50, :53-99, :146-185
   * ``AssignResult`` (fields only)   .../assigners/assign_result.py:8-60
   * ``linear_sum_assignment``        scipy.optimize (call sites hungarian_assigner.py:136, dino_detr_ssod.py:279)
+  * ``O2MAssigner`` / ``O2MAssignResult``  detr_od/core/bbox/assigners/o2m_assigner.py:17-170, o2m_assign_result.py:6-52
+    (the warm-up stage's one-to-many assigner, ``csrc/o2m.hip``)
 and adds ``HungarianAssigner.assign_batch`` -- all (decoder layer x image) problems of a ``loss()`` call
 in two launches and at most one host sync (only to raise scipy's ``ValueError`` on NaN / infeasible input).
 When mmdet/mmcv are importable the classes are registered under the reference's names (see ``registry.py``).
@@ -311,3 +313,83 @@ class HungarianAssigner:
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None, eps=1e-7):
         assert gt_bboxes_ignore is None, "Only case when gt_bboxes_ignore is None is supported."
         return self.assign_batch(bbox_pred[None], cls_pred[None], [gt_bboxes], [gt_labels], [img_meta])[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# one-to-many assigner of the warm-up stage
+# ---------------------------------------------------------------------------------------------
+class O2MAssignResult:
+    """Same public fields as the reference's ``O2MAssignResult`` (o2m_assign_result.py:44-52)."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, assign_metrics, labels=None):
+        self.num_gts = num_gts
+        self.gt_inds = gt_inds
+        self.max_overlaps = max_overlaps
+        self.assign_metrics = assign_metrics
+        self.labels = labels
+        self._extra_properties = {}
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+    def __repr__(self):
+        return (f"<O2MAssignResult(num_gts={self.num_gts}, gt_inds.shape={tuple(self.gt_inds.shape)}, "
+                f"max_overlaps.shape={tuple(self.max_overlaps.shape)})>")
+
+
+class O2MAssigner:
+    """``O2MAssigner(candidate_topk=13)`` -- same constructor and ``assign`` signature as the reference's
+    (o2m_assigner.py:46-60).  ``assign_batch`` solves every (layer, image) problem of a ``loss()`` call in one
+    launch and also returns the warm-up branch's training targets (dino_detr_ssod_head.py:1114-1160)."""
+
+    def __init__(self, candidate_topk=13, debug=False):
+        self.candidate_topk = candidate_topk
+        self.debug = debug
+
+    def assign_batch(self, bbox_preds, cls_probs, gt_bboxes_list, gt_labels_list, img_metas, alpha=1, beta=6,
+                     candidate_topk=None):
+        """bbox_preds (B,Q,4) normalised cxcywh, cls_probs (B,Q,C) PROBABILITIES (``cls_score.sigmoid()``), one gt
+        tensor pair and one img_meta per problem.  Returns dict(gt_inds, labels, max_overlaps, assign_metrics
+        (each (B,Q)), labels_full (B,Q), bbox_targets (B,Q,4), norm_metrics (B,Q), num_gts list)."""
+        _require_cuda(bbox_preds, cls_probs)
+        B, Q, C = cls_probs.shape
+        dev = bbox_preds.device
+        k = self.candidate_topk if candidate_topk is None else candidate_topk
+        counts = [int(g.size(0)) for g in gt_bboxes_list]
+        assert len(counts) == len(gt_labels_list) == len(img_metas) == B
+        bp = bbox_preds.detach().to(torch.float32).contiguous()
+        cp = cls_probs.detach().to(torch.float32).contiguous()
+        gt_b = (torch.cat([g.reshape(-1, 4) for g in gt_bboxes_list]) if B else bp.new_zeros((0, 4)))
+        gt_b = gt_b.detach().to(device=dev, dtype=torch.float32).contiguous()
+        gt_l = (torch.cat([g.reshape(-1).long() for g in gt_labels_list]) if B else bp.new_zeros(0).long())
+        gt_l = gt_l.detach().to(device=dev).contiguous()
+        offs, offs_dev = _offsets(counts, dev)
+        wh = _to_device_async([[m["img_shape"][1], m["img_shape"][0]] for m in img_metas] or [[1, 1]], torch.float32, dev)
+        out = dict(gt_inds=torch.empty((B, Q), dtype=torch.int64, device=dev),
+                   labels=torch.empty((B, Q), dtype=torch.int64, device=dev),
+                   max_overlaps=torch.empty((B, Q), dtype=torch.float32, device=dev),
+                   assign_metrics=torch.empty((B, Q), dtype=torch.float32, device=dev),
+                   labels_full=torch.empty((B, Q), dtype=torch.int64, device=dev),
+                   bbox_targets=torch.empty((B, Q, 4), dtype=torch.float32, device=dev),
+                   norm_metrics=torch.empty((B, Q), dtype=torch.float32, device=dev))
+        with torch.cuda.device(dev):
+            rc = _lib.lib().semidetr_o2m_assign_f32(
+                _lib.current_stream_ptr(), _p(bp), _p(cp), _p(gt_b), _p(gt_l), _p(offs_dev), _p(wh), B, Q, C, offs[-1],
+                max(counts) if counts else 0, int(k), float(alpha), float(beta), _p(out["gt_inds"]), _p(out["labels"]),
+                _p(out["max_overlaps"]), _p(out["assign_metrics"]), _p(out["labels_full"]), _p(out["bbox_targets"]),
+                _p(out["norm_metrics"]))
+        _lib.check(rc, "semidetr_o2m_assign_f32")
+        out["num_gts"] = counts
+        return out
+
+    def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None, alpha=1, beta=6,
+               teacher_assign=False, multiple_pos=False):
+        assert gt_bboxes_ignore is None, "Only case when gt_bboxes_ignore is None is supported."
+        if teacher_assign and multiple_pos:
+            raise NotImplementedError("O2MAssigner: teacher_assign with multiple_pos (dynamic k) has no caller in the "
+                                      "reference and is not built")
+        k = 1 if teacher_assign else self.candidate_topk       # o2m_assigner.py:115-122
+        r = self.assign_batch(bbox_pred[None], cls_pred[None], [gt_bboxes], [gt_labels], [img_meta], alpha, beta, k)
+        return O2MAssignResult(r["num_gts"][0], r["gt_inds"][0], r["max_overlaps"][0], r["assign_metrics"][0],
+                               labels=r["labels"][0])

@@ -1,7 +1,7 @@
 """Registration under the reference's plugin names, for trees where mmcv / mmdet are installed.
 
 The reference instantiates everything through mmcv registries and ``type=`` strings in its configs
-(``@BBOX_ASSIGNERS.register_module()`` hungarian_assigner.py:16, ``@MATCH_COST.register_module()``
+(``@BBOX_ASSIGNERS.register_module()`` hungarian_assigner.py:16, o2m_assigner.py:17, ``@MATCH_COST.register_module()``
 match_cost.py:8,53,146, ``@HOOKS.register_module()`` mean_teacher.py:7).  ``register_all(force=True)``
 replaces those entries with the gfx950 implementations so ``configs/dino_detr`` and ``configs/detr_ssod``
 run unchanged.  mmcv/mmdet are NOT installed in the build image, so this module only does something where
@@ -10,7 +10,7 @@ they exist; importing it elsewhere is harmless (returns the list of names it cou
 
 
 def register_all(force=True):
-    from .matcher import BBoxL1Cost, FocalLossCost, HungarianAssigner, IoUCost
+    from .matcher import BBoxL1Cost, FocalLossCost, HungarianAssigner, IoUCost, O2MAssigner
     from .mean_teacher import MeanTeacher
 
     done, skipped = [], []
@@ -18,11 +18,12 @@ def register_all(force=True):
         from mmdet.core.bbox.builder import BBOX_ASSIGNERS
         from mmdet.core.bbox.match_costs.builder import MATCH_COST
         BBOX_ASSIGNERS.register_module(name="HungarianAssigner", force=force, module=HungarianAssigner)
+        BBOX_ASSIGNERS.register_module(name="O2MAssigner", force=force, module=O2MAssigner)
         for cls in (BBoxL1Cost, FocalLossCost, IoUCost):
             MATCH_COST.register_module(name=cls.__name__, force=force, module=cls)
-        done += ["HungarianAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost"]
+        done += ["HungarianAssigner", "O2MAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost"]
     except ImportError:
-        skipped += ["HungarianAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost"]
+        skipped += ["HungarianAssigner", "O2MAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost"]
     try:
         from mmcv.runner.hooks import HOOKS
         HOOKS.register_module(name="MeanTeacher", force=force, module=MeanTeacher)

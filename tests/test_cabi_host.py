@@ -114,8 +114,17 @@ def test_assigner_surface_and_registry():
     with pytest.raises(KeyError):
         s.HungarianAssigner(cls_cost=dict(type="NoSuchCost"))
     done, skipped = registry.register_all()
-    assert set(done) | set(skipped) == {"HungarianAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost",
+    assert set(done) | set(skipped) == {"HungarianAssigner", "O2MAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost",
                                         "MeanTeacher"}
+    o = s.O2MAssigner()
+    assert o.candidate_topk == 13 and s.O2MAssigner(candidate_topk=5).candidate_topk == 5
+    with pytest.raises(AssertionError, match="gt_bboxes_ignore"):
+        o.assign(torch.zeros(1, 4), torch.zeros(1, 2), torch.zeros(0, 4), torch.zeros(0), {}, gt_bboxes_ignore=1)
+    with pytest.raises(NotImplementedError):
+        o.assign(torch.zeros(1, 4), torch.zeros(1, 2), torch.zeros(0, 4), torch.zeros(0), {}, teacher_assign=True,
+                 multiple_pos=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        o.assign(torch.zeros(20, 4), torch.zeros(20, 2), torch.zeros(1, 4), torch.zeros(1), dict(img_shape=(4, 4, 3)))
     h = s.MeanTeacher(momentum=0.999, interval=1, warm_up=0)
     for meth in ("before_run", "before_train_iter", "after_train_iter", "momentum_update"):
         assert callable(getattr(h, meth))
