@@ -277,6 +277,23 @@ int semidetr_o2m_assign_f32(void *stream, const float *bbox_pred, const float *c
                             int64_t *gt_inds, int64_t *labels, float *max_overlaps, float *assign_metrics,
                             int64_t *labels_full, float *bbox_targets, float *norm_metrics);
 
+/* ---------------------------------------------------------------------------------------------
+ * Task-aligned focal loss of the warm-up stage, fused with the sigmoid in front of it; loss sum and (optionally)
+ * its gradient w.r.t. the logits in one streaming pass, deterministic summation.
+ *
+ * Replaces  task_aigned_focal_loss / TaskAlignedFocalLoss  detr_od/models/losses/task_aligned_focal_loss.py:35-66,:166-200
+ *           as called at  detr_od/models/dense_heads/dino_detr_ssod_head.py:693-694  (prob = cls_scores.sigmoid())
+ *   logits (N,C) fp32 (input_is_prob != 0: they already are probabilities, the reference module's contract, and the
+ *   gradient is d/d prob); labels (N,) int64 in [0, C] (C = background); metrics (N,) fp32 normalised alignment metrics;
+ *   workspace: semidetr_tal_loss_workspace_bytes() bytes of device memory;
+ *   loss_sum (1,) fp32 = sum_ic |s - p|^gamma * BCE(p, s)  (the caller divides by avg_factor / applies loss_weight);
+ *   grad_logits (N,C) fp32 or NULL = d loss_sum / d logits.
+ * ------------------------------------------------------------------------------------------- */
+size_t semidetr_tal_loss_workspace_bytes(void);
+int semidetr_tal_loss_f32(void *stream, const float *logits, const int64_t *labels, const float *metrics,
+                          int64_t num_rows, int num_classes, float gamma, int input_is_prob, void *workspace,
+                          float *loss_sum, float *grad_logits);
+
 #ifdef __cplusplus
 }
 #endif

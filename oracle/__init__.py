@@ -222,3 +222,16 @@ def o2m_targets(gt_inds, max_overlaps, assign_metrics, gt_bboxes, gt_labels, img
     fn(_p(gt_inds), _p(max_overlaps), _p(assign_metrics), _p(gt_bboxes), _p(gt_labels), Q, G, float(img_w), float(img_h),
        int(num_classes), _p(lf), _p(bt), _p(nm))
     return lf[:Q], bt[:Q], nm[:Q]
+
+
+def tal_loss(scores, labels, metrics, gamma=2.0, input_is_prob=True, want_grad=True):
+    """-> (loss_sum float64, grad (N,C) f32 or None); o2m_oracle.c:tal_loss_oracle (task_aligned_focal_loss.py:35-66)."""
+    scores = _c(scores, np.float32)
+    labels, metrics = _c(labels, np.int64), _c(metrics, np.float32)
+    N, C = scores.shape
+    grad = np.zeros_like(scores) if want_grad else None
+    fn = lib().tal_loss_oracle
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+    s = fn(_p(scores), _p(labels), _p(metrics), N, C, float(gamma), int(bool(input_is_prob)), _p(grad))
+    return s, grad

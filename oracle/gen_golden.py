@@ -18,6 +18,7 @@ What is imported from the reference (by file path, with stub registries for the 
     greedy suppression is the published algorithm: PARITY UNPINNED for the keep decisions)
   * detr_ssod/models/utils/bbox_utils.py (Transform2D.transform_bboxes)
   * detr_od/core/bbox/assigners/o2m_assigner.py (O2MAssigner) + o2m_assign_result.py
+  * detr_od/models/losses/task_aligned_focal_loss.py (task_aigned_focal_loss) + mmdet losses/utils.py
 The assignment itself comes from scipy.optimize.linear_sum_assignment (scipy 1.15.3), exactly as
 hungarian_assigner.py:136 calls it.  MeanTeacher / pseudo-label code needs mmcv to import, so those
 fixtures restate mean_teacher.py:46-64 and dino_detr_ssod.py:918-939 with the same torch calls.
@@ -537,6 +538,54 @@ def gen_o2m(tr):
     np.savez_compressed(os.path.join(OUT, "o2m.npz"), **d)
 
 
+def gen_tal():
+    """The reference's own task_aigned_focal_loss (detr_od/models/losses/task_aligned_focal_loss.py:35-66) with mmdet's
+    weight_reduce_loss (losses/utils.py:29-55), both imported by path; gradients by torch.autograd, once w.r.t. the
+    probabilities (the module's contract) and once through the call site's sigmoid (head.py:693-694)."""
+    mmcv = sys.modules.get("mmcv") or types.ModuleType("mmcv")
+    mmcv.jit = lambda **k: (lambda f: f)
+    sys.modules["mmcv"] = mmcv
+    runner = types.ModuleType("mmcv.runner")
+    runner.get_dist_info = lambda: (0, 1)
+    sys.modules["mmcv.runner"] = runner
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda c: c
+    for n in ("mmdet.models", "mmdet.models.losses"):
+        if n not in sys.modules:
+            m = types.ModuleType(n)
+            m.__path__ = []
+            sys.modules[n] = m
+    b = types.ModuleType("mmdet.models.builder")
+    b.LOSSES = _Reg()
+    sys.modules["mmdet.models.builder"] = b
+    _load("mmdet.models.losses.utils", REF + "/thirdparty/mmdetection/mmdet/models/losses/utils.py", "mmdet.models.losses")
+    tal = _load("ref_tal", REF + "/detr_od/models/losses/task_aligned_focal_loss.py")
+    d, names = {}, []
+    g = torch.Generator().manual_seed(53)
+    for name, N, C, npos in (("dino", 900, 80, 90), ("small", 37, 5, 11), ("allbg", 20, 4, 0), ("sat", 64, 3, 20)):
+        logits = torch.randn(N, C, generator=g) * (6.0 if name == "sat" else 2.0) - 2.0
+        labels = torch.full((N,), C, dtype=torch.long)
+        pos = torch.randperm(N, generator=g)[:npos]
+        labels[pos] = torch.randint(0, C, (npos,), generator=g)
+        metric = torch.zeros(N)
+        metric[pos] = torch.rand(npos, generator=g)
+        avg = float(max(metric.sum().item(), 1.0))
+        x = logits.clone().requires_grad_(True)
+        prob = x.sigmoid()
+        prob.retain_grad()
+        loss = tal.task_aigned_focal_loss(prob, labels, metric, None, gamma=2.0, reduction="mean", avg_factor=avg)
+        loss.backward()
+        names.append(name)
+        d[f"{name}.logits"], d[f"{name}.labels"], d[f"{name}.metric"] = logits.numpy(), labels.numpy(), metric.numpy()
+        d[f"{name}.avg_factor"] = np.float64(avg)
+        d[f"{name}.loss"] = np.float64(loss.item())
+        d[f"{name}.grad_prob"], d[f"{name}.grad_logits"] = prob.grad.numpy(), x.grad.numpy()
+    d["names"] = np.asarray(names)
+    np.savez_compressed(os.path.join(OUT, "tal_loss.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     func, modl, mc, tr, _ = import_reference()
@@ -549,6 +598,7 @@ def main():
     gen_nms(tr)
     gen_transform()
     gen_o2m(tr)
+    gen_tal()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

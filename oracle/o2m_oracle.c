@@ -118,3 +118,29 @@ void o2m_targets_oracle(const int64_t *gt_inds, const float *max_overlaps, const
     }
     free(mm); free(mi); free(has);
 }
+
+/* task_aigned_focal_loss (task_aligned_focal_loss.py:35-66) on probabilities or logits: returns the loss SUM and
+ * writes d sum / d input when grad != NULL (BCE backward as torch: (p - s) / max((1 - p) p, 1e-12)). */
+double tal_loss_oracle(const float *scores, const int64_t *labels, const float *metrics, int64_t N, int C, float gamma,
+                       int input_is_prob, float *grad)
+{
+    double sum = 0.0;
+    for (int64_t i = 0; i < N; ++i)
+        for (int c = 0; c < C; ++c) {
+            const float x = scores[i * C + c];
+            const float s = labels[i] == c ? metrics[i] : 0.f;
+            const float p = input_is_prob ? x : 1.0f / (1.0f + expf(-x));
+            const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
+            const float ce = -(s * lp + (1.0f - s) * l1p);
+            const float d = s - p, ad = fabsf(d);
+            const float mod = gamma == 2.0f ? ad * ad : powf(ad, gamma);
+            sum += (double)(mod * ce);
+            if (grad) {
+                const float dmod = gamma == 2.0f ? -2.0f * d : (ad > 0.f ? -gamma * powf(ad, gamma - 1.0f) * (d > 0.f ? 1.f : -1.f) : 0.f);
+                const float dce = (p - s) / fmaxf((1.0f - p) * p, 1e-12f);
+                const float dp = dmod * ce + mod * dce;
+                grad[i * C + c] = input_is_prob ? dp : dp * (p * (1.0f - p));
+            }
+        }
+    return sum;
+}

@@ -25,6 +25,13 @@ def register_all(force=True):
     except ImportError:
         skipped += ["HungarianAssigner", "O2MAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost"]
     try:
+        from mmdet.models.builder import LOSSES
+        from .losses import TaskAlignedFocalLoss
+        LOSSES.register_module(name="TaskAlignedFocalLoss", force=force, module=TaskAlignedFocalLoss)
+        done.append("TaskAlignedFocalLoss")
+    except ImportError:
+        skipped.append("TaskAlignedFocalLoss")
+    try:
         from mmcv.runner.hooks import HOOKS
         HOOKS.register_module(name="MeanTeacher", force=force, module=MeanTeacher)
         done.append("MeanTeacher")

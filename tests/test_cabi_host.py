@@ -115,7 +115,7 @@ def test_assigner_surface_and_registry():
         s.HungarianAssigner(cls_cost=dict(type="NoSuchCost"))
     done, skipped = registry.register_all()
     assert set(done) | set(skipped) == {"HungarianAssigner", "O2MAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost",
-                                        "MeanTeacher"}
+                                        "MeanTeacher", "TaskAlignedFocalLoss"}
     o = s.O2MAssigner()
     assert o.candidate_topk == 13 and s.O2MAssigner(candidate_topk=5).candidate_topk == 5
     with pytest.raises(AssertionError, match="gt_bboxes_ignore"):
