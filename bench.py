@@ -334,6 +334,52 @@ def module_bench(dev, iters=10):
     return res
 
 
+def warmup_stage_bench(dev, iters=20):
+    """Next-row evidence: the warm-up stage's matcher and classification loss for one
+    loss() call of the SSOD step -- 7 layers x 5 images = 35 one-to-many assignment problems (Q=900, G~U[1,15]) in
+    one launch, and the fused task-aligned focal loss (sigmoid + loss + gradient) over the 35 x 900 x 80 logits."""
+    import semi_detr_amd as sda
+    g = torch.Generator(device=dev).manual_seed(7)
+    rng = np.random.default_rng(7)
+    B, Q, C = 35, NUM_QUERY, 80
+    bp = torch.cat([torch.rand(B, Q, 2, generator=g, device=dev), torch.rand(B, Q, 2, generator=g, device=dev) * 0.3 + 0.02], -1)
+    logits = torch.randn(B, Q, C, generator=g, device=dev) * 2 - 3
+    gts, labs, metas = [], [], []
+    for _ in range(B):
+        G = int(rng.integers(1, 16))
+        xy = torch.rand(G, 2, generator=g, device=dev) * torch.tensor([1000.0, 560.0], device=dev)
+        wh = torch.rand(G, 2, generator=g, device=dev) * torch.tensor([300.0, 220.0], device=dev) + 16
+        gts.append(torch.cat([xy, xy + wh], -1))
+        labs.append(torch.randint(0, C, (G,), generator=g, device=dev))
+        metas.append(dict(img_shape=(800, 1333, 3)))
+    asg, crit = sda.O2MAssigner(), sda.TaskAlignedFocalLoss()
+    x = logits.view(-1, C).clone().requires_grad_(True)
+
+    def assign():
+        return asg.assign_batch(bp, logits.sigmoid(), gts, labs, metas)
+
+    def loss(t):
+        x.grad = None
+        crit.forward_logits(x, t["labels_full"].view(-1), t["norm_metrics"].view(-1), avg_factor=10.0).backward()
+
+    t = assign()
+    loss(t)
+    res = {}
+    for name, fn in (("o2m_assign_batch_us", assign), ("tal_loss_fwd_bwd_us", lambda: loss(t))):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) * 1e3 / iters
+    res["tal_loss_alg_gbs"] = 2 * 4 * x.numel() / (res["tal_loss_fwd_bwd_us"] * 1e-6) / 1e9
+    res["positives"] = int((t["gt_inds"] > 0).sum())
+    res["what"] = "35 problems x (900 queries, 80 classes, G~U[1,15]); event-timed incl. host-side packing"
+    return res
+
+
 def cpu_baseline():
     """The oracle (a C port of the reference arithmetic; the reference itself has no native CPU path --
     ms_deform_attn_cpu.cpp:26,39 only raises) timed on this box's host cores with OpenMP on a bounded sample:
@@ -452,6 +498,7 @@ def main():
         if not args.no_micro:
             out["microbench"] = microbench(dev)
             out["module_fused_prologue"] = module_bench(dev)
+            out["warmup_stage"] = warmup_stage_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
