@@ -235,25 +235,91 @@ class Workload:
         return agg
 
 
+def _graph_time(fn, per_graph=20, reps=9, replays=5):
+    """Device time per call: the launches captured once in a HIP graph and replayed (what a training step sees --
+    launches are queued ahead of the GPU).  Returns (median, p10, p90) in microseconds over `reps` timings."""
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        for _ in range(per_graph):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(replays):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / (replays * per_graph))
+    del graph
+    return float(np.median(ts)), float(np.percentile(ts, 10)), float(np.percentile(ts, 90))
+
+
+def hbm_stream_peak(dev):
+    """Measured streaming rate of this GPU (device-to-device copy of 1 GiB: read + write), GB/s."""
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def _msda_case(dev, levels, N, Lq, encoder):
+    shapes = torch.as_tensor(levels, dtype=torch.long, device=dev)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    Sx, Lx = int((shapes[:, 0] * shapes[:, 1]).sum()), len(levels)
+    value = torch.rand(N, Sx, M, D, device=dev) * 0.01
+    if encoder:      # reference-point-centred: pixel centre + N(0, (2 px)^2) on every level (SURVEY.md section 8(d))
+        ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h,
+                                                    (torch.arange(w, device=dev) + 0.5) / w, indexing="ij"), -1)
+                         .flip(-1).reshape(-1, 2) for h, w in levels])
+        wh = torch.tensor([[w, h] for h, w in levels], dtype=torch.float32, device=dev)
+        loc = ref.view(1, Sx, 1, 1, 1, 2) + torch.randn(N, Sx, M, Lx, P, 2, device=dev) * (2.0 / wh).view(1, 1, 1, Lx, 1, 2)
+        Lq = Sx
+    else:
+        loc = torch.rand(N, Lq, M, Lx, P, 2, device=dev)
+    attn = torch.rand(N, Lq, M, Lx, P, device=dev) + 1e-5
+    attn = attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    gout = torch.ones(N, Lq, M * D, device=dev)
+    return value, shapes, starts, loc.contiguous(), attn, gout, Sx, Lx, Lq
+
+
+def _alg_bytes(N, Sx, Lx, Lq, backward):
+    e = 4
+    K = N * Lq * M * Lx * P
+    vmap, g4 = N * Sx * M * D * e, 4 * K * D * e
+    vt, bl, ba, bo = min(vmap, g4), K * 2 * e, K * e, N * Lq * M * D * e
+    return (bo + vt + bl + ba + bl + ba + vmap + vt) if backward else (vt + bl + ba + bo)
+
+
 def microbench(dev, iters=200, warm=20):
-    """BASELINE.json metric shape: N=2, Lq=300, L=4, M=8, P=4, D=32, S=22223; test.py input distributions."""
+    """BASELINE.json metric shape: N=2, Lq=300, L=4, M=8, P=4, D=32, S=22223; test.py input distributions
+    (seed 3).  Plus the secondary shapes SURVEY.md section 8(d) names, each fwd / bwd as median [p10, p90]."""
     import MultiScaleDeformableAttention as MSDA
     torch.manual_seed(3)
     N, Lq = 2, 300
-    shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
-    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
-    value = torch.rand(N, S, M, D, device=dev) * 0.01
-    loc = torch.rand(N, Lq, M, L, P, 2, device=dev)
-    attn = torch.rand(N, Lq, M, L, P, device=dev) + 1e-5
-    attn = attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
-    gout = torch.ones(N, Lq, M * D, device=dev)
+    value, shapes, starts, loc, attn, gout, _, _, _ = _msda_case(dev, LEVELS, N, Lq, False)
     res = {}
     for name, fn in (("fwd", lambda: MSDA.ms_deform_attn_forward(value, shapes, starts, loc, attn, 64)),
                      ("bwd", lambda: MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn, gout, 64))):
         for _ in range(warm):
             fn()
         # (a) eager launches from Python: includes the host cost of each call (allocation + ctypes), which at
-        #     this size is larger than the kernel itself
+        #     this size is larger than the forward kernel itself
         ts = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -264,35 +330,31 @@ def microbench(dev, iters=200, warm=20):
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3 / (iters // 5))
         res[name + "_eager_us"] = float(np.median(ts))
-        # (b) the same launches captured once in a HIP graph and replayed: device time per call, which is
-        #     what a training step sees (launches are queued ahead of the GPU)
-        per_graph = 20
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.cuda.graph(graph):
-            for _ in range(per_graph):
-                fn()
-        graph.replay()
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(7):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                graph.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) * 1e3 / (5 * per_graph))
-        res[name + "_us"] = float(np.median(ts))
-        del graph
+        # (b) graph replay: device time per call
+        res[name + "_us"], res[name + "_p10_us"], res[name + "_p90_us"] = _graph_time(fn)
     res["fwd_bwd_us"] = res["fwd_us"] + res["bwd_us"]
     b = msda_alg_bytes(N, Lq, False) + msda_alg_bytes(N, Lq, True)
     res["alg_bytes"] = b
     res["frac_hbm_peak"] = b / (res["fwd_bwd_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9)
+    peak = hbm_stream_peak(dev)
+    res["hbm_stream_measured_gbs"] = peak
+    res["frac_hbm_measured"] = b / (res["fwd_bwd_us"] * 1e-6) / (peak * 1e9)
+    sec = {}
+    five = LEVELS + [(7, 11)]
+    for key, levels, n, lq, enc in (("decoder_bs2_Lq1100", LEVELS, 2, 1100, False), ("encoder_bs2_Lq22223", LEVELS, 2, 0, True),
+                                    ("five_level_bs2_Lq900", five, 2, 900, False)):
+        v, sh, st, lo, at, go, Sx, Lx, lq = _msda_case(dev, levels, n, lq, enc)
+        f = lambda: MSDA.ms_deform_attn_forward(v, sh, st, lo, at, 64)           # noqa: E731
+        bw = lambda: MSDA.ms_deform_attn_backward(v, sh, st, lo, at, go, 64)     # noqa: E731
+        f(); bw()
+        tf, tb = _graph_time(f, reps=5), _graph_time(bw, reps=5)
+        bf, bb = _alg_bytes(n, Sx, Lx, lq, False), _alg_bytes(n, Sx, Lx, lq, True)
+        g4 = 4 * n * lq * M * Lx * P * D * 4
+        sec[key] = {"fwd_us": tf[0], "fwd_p10_p90_us": [tf[1], tf[2]], "bwd_us": tb[0], "bwd_p10_p90_us": [tb[1], tb[2]],
+                    "fwd_alg_gbs": bf / (tf[0] * 1e-6) / 1e9, "bwd_alg_gbs": bb / (tb[0] * 1e-6) / 1e9,
+                    "fwd_gather_rate_gbs": g4 / (tf[0] * 1e-6) / 1e9}
+        del v, lo, at, go
+    res["secondary_shapes"] = sec
     return res
 
 
