@@ -157,6 +157,41 @@ def gen_msda(func):
     return d
 
 
+FULL_LEVELS = [(100, 167), (50, 84), (25, 42), (13, 21)]
+
+
+def full_inputs(seed=3):
+    """Inputs of the BASELINE.json micro-benchmark shape (N=2, Lq=300, L=4, M=8, P=4, D=32, S=22223), test.py's
+    distributions (test.py:33-36).  45 MB: regenerated from the seed on both sides (torch's CPU generator is
+    deterministic), never committed.  tests/test_gpu_msda.py repeats exactly these calls."""
+    g = torch.Generator().manual_seed(seed)
+    N, M, D, Lq, L, P = 2, 8, 32, 300, 4, 4
+    S = sum(h * w for h, w in FULL_LEVELS)
+    value = torch.rand(N, S, M, D, generator=g) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    attn = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
+    attn = attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    gout = torch.rand(N, Lq, M * D, generator=g)
+    return value, loc, attn, gout
+
+
+def gen_msda_full(func):
+    """The reference's CPU path at the full micro-benchmark shape: outputs and the two small gradients whole,
+    grad_value as every 61st row + per-(image, level) sums (the tensor itself is 45 MB)."""
+    value, loc, attn, gout = full_inputs()
+    v, lo, a = [t.clone().requires_grad_(True) for t in (value, loc, attn)]
+    sh = torch.as_tensor(FULL_LEVELS, dtype=torch.long)
+    out = func.ms_deform_attn_core_pytorch(v, sh, lo, a)
+    out.backward(gout)
+    gv = v.grad.reshape(2, -1, 8 * 32)
+    starts = np.concatenate([[0], np.cumsum([h * w for h, w in FULL_LEVELS])])
+    level_sums = np.asarray([[gv[n, starts[l]:starts[l + 1]].double().sum().item() for l in range(4)] for n in range(2)])
+    np.savez_compressed(os.path.join(OUT, "msda_full.npz"), out=out.detach().numpy(), gloc=lo.grad.numpy(),
+                        gattn=a.grad.numpy(), gvalue_rows=gv[:, ::61].numpy(), gvalue_level_sums=level_sums,
+                        input_checksum=np.asarray([value.double().sum().item(), loc.double().sum().item(),
+                                                   attn.double().sum().item(), gout.double().sum().item()]))
+
+
 def gen_module(modl, func):
     """Pins MSDeformAttn.forward arithmetic around the op (modules/ms_deform_attn.py:78-126)."""
     func.MSDeformAttnFunction.apply = staticmethod(
@@ -590,6 +625,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     func, modl, mc, tr, _ = import_reference()
     gen_msda(func)
+    gen_msda_full(func)
     gen_module(modl, func)
     gen_cost(mc, tr)
     gen_lsap()

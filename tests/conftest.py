@@ -87,3 +87,37 @@ def kink_mask(loc, shapes):
     tol = 1e-9 if loc.dtype == np.float64 else 1e-4
     m = (np.abs(h - np.round(h)) < tol) | (np.abs(w - np.round(w)) < tol)
     return np.broadcast_to(m[..., None], loc.shape)
+
+
+FULL_LEVELS = [(100, 167), (50, 84), (25, 42), (13, 21)]
+
+
+def full_shape_inputs(seed=3):
+    """Exactly oracle/gen_golden.py:full_inputs -- the BASELINE.json micro-benchmark shape (N=2, Lq=300, L=4, M=8,
+    P=4, D=32, S=22223) regenerated from the seed (torch's CPU generator is deterministic); tests/golden/msda_full.npz
+    holds the reference's outputs for these inputs and a checksum of the inputs themselves."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    N, M, D, Lq, L, P = 2, 8, 32, 300, 4, 4
+    S = sum(h * w for h, w in FULL_LEVELS)
+    value = torch.rand(N, S, M, D, generator=g) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g)
+    attn = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
+    attn = attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    gout = torch.rand(N, Lq, M * D, generator=g)
+    return value, loc, attn, gout
+
+
+def check_full_shape(out, gv, gl, ga, loc, golden):
+    """out / gv / gl / ga (numpy) of the full micro-benchmark shape against the reference's CPU path."""
+    shapes = np.asarray(FULL_LEVELS, np.int64)
+    np.testing.assert_allclose(out, golden["out"], rtol=0, atol=2e-7)          # north-star bar: 1e-4
+    np.testing.assert_allclose(ga, golden["gattn"], rtol=0, atol=2e-7)
+    ok = ~(kink_mask(loc, shapes) | skipped_sample_mask(loc, shapes))
+    scale = np.abs(golden["gloc"]).max()
+    np.testing.assert_allclose(gl[ok], golden["gloc"][ok], rtol=0, atol=2e-5 * scale)
+    gv = gv.reshape(2, -1, 256)
+    np.testing.assert_allclose(gv[:, ::61], golden["gvalue_rows"], rtol=0, atol=2e-6)
+    starts = np.concatenate([[0], np.cumsum([h * w for h, w in FULL_LEVELS])])
+    sums = np.asarray([[gv[n, starts[l]:starts[l + 1]].astype(np.float64).sum() for l in range(4)] for n in range(2)])
+    np.testing.assert_allclose(sums, golden["gvalue_level_sums"], rtol=2e-6)

@@ -223,6 +223,17 @@ def test_microbench_shape_vs_oracle():
     assert np.abs(ga - o_ga).max() < 1e-5
 
 
+def test_microbench_shape_vs_reference_fixture():
+    """The same shape against the REFERENCE's own CPU path (tests/golden/msda_full.npz; inputs regenerated from
+    the seed exactly as oracle/gen_golden.py:full_inputs does)."""
+    import os
+    from conftest import FULL_LEVELS, check_full_shape, full_shape_inputs
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msda_full.npz"))
+    value, loc, attn, gout = [t.numpy() for t in full_shape_inputs()]
+    out, gv, gl, ga = _run(value, np.asarray(FULL_LEVELS, np.int64), loc, attn, gout)
+    check_full_shape(out, gv, gl, ga, loc, golden)
+
+
 @pytest.mark.parametrize("Lq", [300, 1100, 22223])
 def test_full_size_properties(Lq):
     """Size-independent properties at decoder and encoder scale (bs=2):

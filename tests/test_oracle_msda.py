@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import Golden, kink_mask, skipped_sample_mask
+from conftest import Golden, check_full_shape, full_shape_inputs, kink_mask, skipped_sample_mask, FULL_LEVELS
 
 CASES = Golden("msda.npz").names()
 
@@ -44,3 +44,17 @@ def test_oracle_zero_outside_and_linearity():
     a = oracle.msda_forward(value, shapes, loc, attn)
     b = oracle.msda_forward(2 * value, shapes, loc, attn)
     np.testing.assert_allclose(b, 2 * a, rtol=1e-14)
+
+
+def test_oracle_full_microbench_shape_matches_reference():
+    """The BASELINE.json metric shape itself (N=2, Lq=300, S=22223): inputs regenerated from the seed, outputs of the
+    reference's CPU path committed whole (out, grad_loc, grad_attn) / sampled + per-level sums (grad_value)."""
+    import os
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msda_full.npz"))
+    value, loc, attn, gout = [t.numpy() for t in full_shape_inputs()]
+    chk = [float(a.astype(np.float64).sum()) for a in (value, loc, attn, gout)]
+    np.testing.assert_allclose(chk, golden["input_checksum"], rtol=1e-12)      # same inputs as the generator saw
+    shapes = np.asarray(FULL_LEVELS, np.int64)
+    out = oracle.msda_forward(value, shapes, loc, attn)
+    gv, gl, ga = oracle.msda_backward(value, shapes, loc, attn, gout)
+    check_full_shape(out, gv, gl, ga, loc, golden)
