@@ -348,14 +348,24 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
 {
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * kD, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    if ((Lq == S && P == kPT && S < (1 << 24) && g_bwd_variant == 0) || g_bwd_variant == 64 || g_bwd_variant == 65) {
+    if ((Lq == S && P == kPT && S < (1 << 24) && g_bwd_variant == 0) || g_bwd_variant == 64 || g_bwd_variant == 65 || g_bwd_variant == 66 || g_bwd_variant == 67) {
         SEMIDETR_REQUIRE(Lq == S && P == kPT && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the windowed kernel needs num_query == spatial_size < 2^24 and num_point == 4");
         {   // gather half: the two small gradients, streams like the forward
             const int gt = (Lq + 31) / 32;
             const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
-            hipLaunchKernelGGL(msda_bwd_gather_d32<IO>, dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
-                               grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
+            // DINO (L * P == 16): sample loop unrolled, results in registers, 8 x 4 query patches like the forward;
+            // measured at the encoder shape, bs 4: generic strips 370 us, unrolled strips 346 us; 66 / 67 force them
+            const int gbound = (S + 31) / 32 * 5 / 4 + 4 * L;      // patch grid hint, see launch_fast_forward
+            if (L * P == 16 && g_bwd_variant != 66 && g_bwd_variant != 67)
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 804>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
+                                   st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
+            else if (L * P == 16 && g_bwd_variant == 67)
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
+                                   grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
+            else
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
+                                   grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
         }
         // patches are enumerated on the device (the level table lives in device memory); a workgroup takes

@@ -33,6 +33,13 @@ struct LocAttnIO {
         gattn[row * LP + k] = res.x;
         *reinterpret_cast<float2 *>(gloc + (row * LP + k) * 2) = make_float2(res.y, res.z);
     }
+    // same, for callers that hold the row's sum_j a_j g_j already (unused here)
+    __device__ __forceinline__ void store_with_dot(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                                   const float4 res, float dot) const
+    {
+        (void)dot;
+        store(row, nq, LP, k, l, P, H, W, res, nullptr);
+    }
 };
 
 struct RawIO {
@@ -65,6 +72,12 @@ struct RawIO {
             dot = 0.f;
             for (int j = 0; j < LP; ++j) dot += row_res[j].w * row_res[j].x;
         }
+        store_with_dot(row, nq, LP, k, l, P, H, W, res, dot);
+    }
+    // dot = sum_j a_j g_j over the row (softmax backward), supplied by the caller
+    __device__ __forceinline__ void store_with_dot(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+                                                   const float4 res, float dot) const
+    {
         glogit[row * LP + k] = res.w * (res.x - dot);
         float2 g;
         if (ref_dim == 2) {
@@ -368,7 +381,12 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
 // sample, NO grad_value scatter.  Same tiling / LDS records / 8-lane x float4 loads as msda_fwd_d32<1>; the
 // three channel sums per sample are 3 DPP steps inside the 8-lane group.  Streams like the forward (no
 // atomics, no per-level barriers), used together with the owner-computes scatter kernel below.
-template <typename IO = LocAttnIO>
+// KLP = L * P at compile time (16: the DINO configuration) or 0.  With KLP the sample loop is fully unrolled, the
+// three sums of sample k stay in the registers of lane k % 8 of the group (no LDS store inside the loop, so the
+// compiler can keep 16 corner loads in flight like the forward does) and go to global memory straight from there.
+// PATCH = PH * 100 + PW: the 32 queries of a workgroup are a patch of one level (num_query == spatial_size), as in
+// the forward; 0: 32 consecutive queries.
+template <typename IO = LocAttnIO, int KLP = 0, int PATCH = 0>
 __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
@@ -386,13 +404,24 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
         lev_h[threadIdx.x] = (float)shapes[2 * threadIdx.x];
         lev_w[threadIdx.x] = (float)shapes[2 * threadIdx.x + 1];
     }
+    constexpr int PH = PATCH / 100, PW = PATCH % 100;
+    static_assert(PATCH == 0 || PH * PW == RPB, "a patch holds exactly the workgroup's rows");
+    Patch pt = {0, 0, 0, 0, 0};
+    // PATCH: tiles_per_image is a grid sizing hint; a workgroup takes patches slot, slot + hint, ... (see the forward)
+    for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
+    if (PATCH) {
+        pt = find_patch<PH ? PH : 1, PW ? PW : 1>(tile, shapes, starts, L);
+        if (pt.Hq == 0) return;
+        __syncthreads();      // previous patch done with the LDS records
+    }
+    auto query_of = [&](int rr_) { return PATCH ? patch_query<PW ? PW : 1>(pt, rr_) : (t.q0 + rr_ < Lq ? t.q0 + rr_ : -1); };
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
-        const int q = t.q0 + r;
+        const int q = query_of(r);
         unsigned off[4] = {kOob, kOob, kOob, kOob};
         const int l = k / P;
         float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
-        if (q < Lq) {
+        if (q >= 0) {
             const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
             const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
             float x, y, lw, lh;
@@ -410,13 +439,70 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
     __syncthreads();
 
     const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
-    const int q = t.q0 + r;
+    const int q = query_of(r);
     const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
     const unsigned lane_b = (unsigned)(t.m * kD + 4 * j) * 4u;
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < Lq) go = *reinterpret_cast<const float4 *>(gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j);
+    if (q >= 0) go = *reinterpret_cast<const float4 *>(gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j);
     const int4 *ro = rec_off + r * LPP;
     float4 *rp = rec_p + r * LPP;
+    if constexpr (KLP > 0) {
+        static_assert(KLP % 8 == 0 && KLP <= 32, "results are spread over the 8 lanes of a group");
+        constexpr int kB = 4;                      // samples per batch: 16 corner loads in flight
+        float4 mine[KLP / 8];
+#pragma unroll
+        for (int i = 0; i < KLP / 8; ++i) mine[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int P_ = KLP / L;                    // == P (checked by the launcher)
+#pragma unroll
+        for (int k0 = 0; k0 < KLP; k0 += kB) {
+            int4 o[kB];
+            float4 pr[kB], v[kB][4];
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                o[u] = ro[k0 + u];
+                pr[u] = rp[k0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                v[u][0] = buf_ld4(vr, (unsigned)o[u].x + lane_b);
+                v[u][1] = buf_ld4(vr, (unsigned)o[u].y + lane_b);
+                v[u][2] = buf_ld4(vr, (unsigned)o[u].z + lane_b);
+                v[u][3] = buf_ld4(vr, (unsigned)o[u].w + lane_b);
+            }
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const int k = k0 + u;
+                const float lw = pr[u].x, lh = pr[u].y, a = pr[u].z;
+                const int l = __float_as_int(pr[u].w);
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                auto dot4 = [&](const float4 &vv) { return go.x * vv.x + go.y * vv.y + go.z * vv.z + go.w * vv.w; };
+                const float d1 = dot4(v[u][0]), d2 = dot4(v[u][1]), d3 = dot4(v[u][2]), d4 = dot4(v[u][3]);
+                float pa = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
+                float px = a * (hh * (d2 - d1) + lh * (d4 - d3));
+                float py = a * (hw * (d3 - d1) + lw * (d4 - d2));
+                pa = group8_sum(pa);
+                px = group8_sum(px);
+                py = group8_sum(py);
+                if ((k & 7) == j) mine[k >> 3] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, a);
+            }
+        }
+        float dot = 0.f;                           // fused epilogue: sum_k a_k g_k over the row
+        if (IO::kSoftmax) {
+#pragma unroll
+            for (int i = 0; i < KLP / 8; ++i) dot += mine[i].w * mine[i].x;
+            dot = group8_sum(dot);
+        }
+        if (q >= 0) {
+            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
+#pragma unroll
+            for (int i = 0; i < KLP / 8; ++i) {
+                const int k = j + 8 * i, l = k / P_;
+                io.store_with_dot(row, nq, LP, k, l, P_, (int)lev_h[l], (int)lev_w[l], mine[i], dot);
+            }
+        }
+        if (!PATCH) return;
+        continue;
+    }
     // Batches of kGU samples, unrolled by hand: the result store into rec_p would otherwise keep the compiler
     // from hoisting the next samples' record reads / corner loads above it (4 * kGU loads in flight per lane; measured on MI355X at the encoder shape, bs 4: kGU 1 / 2 / 4 -> 370 / 389 / 375 us, so 1).
     constexpr int kGU = 1;
@@ -457,11 +543,13 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
     __syncthreads();
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
         const int rr = s / LP, k = s - rr * LP;
-        const int qq = t.q0 + rr;
-        if (qq >= Lq) continue;
+        const int qq = query_of(rr);
+        if (qq < 0) continue;
         const int64_t nq = (int64_t)t.n * Lq + qq, row = nq * M + t.m;
         const int l = k / P;
         io.store(row, nq, LP, k, l, P, (int)lev_h[l], (int)lev_w[l], rec_p[rr * LPP + k], rec_p + rr * LPP);
+    }
+    if (!PATCH) return;
     }
 }
 
