@@ -21,7 +21,7 @@ def stats(d):
     rows = list(csv.DictReader(open(f)))
     print(f"# rocprofv3 --kernel-trace --stats ; source {f.split('gpurun_out/')[-1]}")
     print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}")
-    for r in rows[:25]:
+    for r in rows[:60]:
         print(f"{short(r['Name']):70s} {int(r['Calls']):6d} {float(r['AverageNs'])/1e3:10.1f} "
               f"{float(r['TotalDurationNs'])/1e6:10.2f} {float(r['Percentage']):6.2f}")
 
