@@ -327,10 +327,12 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
         const int bound = (S + 31) / 32 * 5 / 4 + 4 * L;
         SEMIDETR_REQUIRE((int64_t)N * bound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
         const size_t lds = (size_t)32 * (L * P + 1) * 32;
-        // measured at the 800x1333 encoder shape, bs 4: strips 299 us, 4x8 284, 8x4 281, 2x16 286
+        // measured at the 800x1333 encoder shape, bs 4, with the head rotation of tile_of_block: 4x8 246 us, 8x4 252,
+        // 2x16 253 (before the rotation: strips 299, 4x8 284, 8x4 281, 2x16 286)
         if (g_fwd_variant == 408) LAUNCH_FWD(1, 4, 408, bound);
         else if (g_fwd_variant == 216) LAUNCH_FWD(1, 4, 216, bound);
-        else LAUNCH_FWD(1, 4, 804, bound);
+        else if (g_fwd_variant == 804) LAUNCH_FWD(1, 4, 804, bound);
+        else LAUNCH_FWD(1, 4, 408, bound);
         return semidetr::launch_status("msda_fwd_d32<patch>");
     }
     const int unroll = g_fwd_variant >= 10 && g_fwd_variant < 100 ? g_fwd_variant / 10 : 4;
@@ -358,7 +360,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             // measured at the encoder shape, bs 4: generic strips 370 us, unrolled strips 346 us; 66 / 67 force them
             const int gbound = (S + 31) / 32 * 5 / 4 + 4 * L;      // patch grid hint, see launch_fast_forward
             if (L * P == 16 && g_bwd_variant != 66 && g_bwd_variant != 67)
-                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 804>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
                                    st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
             else if (L * P == 16 && g_bwd_variant == 67)
                 hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,

@@ -133,8 +133,14 @@ __device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, 
     return expf(raw - mx) / sum;
 }
 
-// Workgroup -> (n, query tile, m): m fastest so that blockIdx % 8 == m % 8 when M % 8 == 0 (L2 affinity,
-// speed only -- correctness never depends on placement).
+// Workgroup -> (n, query tile, m).  Consecutive workgroups take consecutive heads, and the head of a given slot is
+// rotated every kHeadRun tiles.  Why: rows of one head are M*128 bytes apart, so with M == 8 they fall into only
+// 1/8 of the L1's sets (64 sets x 4 ways x 128 B) -- a CU whose resident workgroups all work on the SAME head
+// (what "blockIdx % 8 == head", i.e. head <-> XCD affinity, gives) sees a 4 KB L1.  With the rotation the ~6
+// workgroups resident on a CU work on different heads and use most of it, while runs of adjacent tiles still
+// share head and XCD (L2).  Measured at the encoder shape, bs 4: forward 284 -> 254 us; run lengths 32..512 are
+// equivalent, 1 gives 278, >= 2048 no effect.  Speed only -- any bijection is correct.
+constexpr int kHeadRun = 64;
 struct Tile {
     int n, q0, m;
 };
@@ -142,8 +148,8 @@ __device__ __forceinline__ Tile tile_of_block(int M, int tiles_per_image, int ro
 {
     const int b = blockIdx.x;
     Tile t;
-    t.m = b % M;
     const int r = b / M;
+    t.m = (b % M + r / kHeadRun) % M;
     t.q0 = (r % tiles_per_image) * rows_per_block;
     t.n = r / tiles_per_image;
     return t;
@@ -576,6 +582,7 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
 // ---------------------------------------------------------------------------------------------
 constexpr int kWinThreads = 512;                        // 8 wavefronts = 32 streams of 16 lanes
 constexpr int kPT = 4;                                  // num_point (compile time)
+constexpr int kScatterHeadRun = 16;                     // head rotation, see tile_of_block
 
 // TH x TW = query patch (pixels), WH x WW = value-row window per sampling level (both compile time).
 // Every thread owns SPT = TH*TW*4 / 512 (query, point) samples of the patch.
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
     constexpr int P = kPT;
     const int Lq = S, LP = L * P, rs = M * kD;
     const int b = blockIdx.x;
-    const int m = b % M;
+    const int m = (b % M + (b / M) / kScatterHeadRun) % M;
     const int slot = (b / M) % tiles_bound, n = (b / M) / tiles_bound;
     const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
 
