@@ -134,12 +134,16 @@ __device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, 
 }
 
 // Workgroup -> (n, query tile, m).  Consecutive workgroups take consecutive heads, and the head of a given slot is
-// rotated every kHeadRun tiles.  Why: rows of one head are M*128 bytes apart, so with M == 8 they fall into only
-// 1/8 of the L1's sets (64 sets x 4 ways x 128 B) -- a CU whose resident workgroups all work on the SAME head
-// (what "blockIdx % 8 == head", i.e. head <-> XCD affinity, gives) sees a 4 KB L1.  With the rotation the ~6
-// workgroups resident on a CU work on different heads and use most of it, while runs of adjacent tiles still
-// share head and XCD (L2).  Measured at the encoder shape, bs 4: forward 284 -> 254 us; run lengths 32..512 are
-// equivalent, 1 gives 278, >= 2048 no effect.  Speed only -- any bijection is correct.
+// rotated every kHeadRun tiles.  Why: rows of one head are M*128 bytes apart, so with M == 8 all addresses one head
+// touches share bits [9:7].  Workgroups go round robin to the 8 XCDs, so "blockIdx % 8 == head" pins each XCD to
+// ONE such address class for the whole launch -- its L2 serves every request from a fraction of its channels.
+// With the rotation an XCD works on ~3 heads at any time (runs of adjacent tiles still share head and XCD, i.e.
+// their halo rows stay in one L2).  Measured at the encoder shape, bs 4 (rocprofv3 PMC): same L1 traffic and hit
+// rate (91 M accesses, 15.4 M L1->L2 requests), L2 misses even UP 3.5 M -> 4.9 M, yet forward 286 -> 248 us, gather
+// 341 -> 320 us, decoder forward 24.7 -> 20.8 us: the gain is L2 bandwidth, not hit rate.  Run lengths 2..512 are
+// equivalent (254-260 us), 1 (adjacent tiles on different XCDs) gives 278, >= 2048 no rotation in practice; giving
+// every XCD all 8 heads of a contiguous eighth of the tiles was as slow as no rotation.  A head-major copy of the
+// value map (N,M,S,D) brought nothing on top.  Speed only -- any bijection is correct.
 constexpr int kHeadRun = 64;
 struct Tile {
     int n, q0, m;
