@@ -6,6 +6,7 @@
 import collections
 import csv
 import glob
+import os
 import re
 import sys
 
@@ -17,7 +18,7 @@ def short(name):
 
 
 def stats(d):
-    f = glob.glob(d + "/**/*_kernel_stats.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)     # newest run
     rows = list(csv.DictReader(open(f)))
     print(f"# rocprofv3 --kernel-trace --stats ; source {f.split('gpurun_out/')[-1]}")
     print(f"{'kernel':70s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}")
@@ -27,7 +28,7 @@ def stats(d):
 
 
 def pmc(d, counter):
-    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(d + "/**/*_counter_collection.csv", recursive=True), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
