@@ -141,7 +141,9 @@ __device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, 
 // their halo rows stay in one L2).  Measured at the encoder shape, bs 4 (rocprofv3 PMC): same L1 traffic and hit
 // rate (91 M accesses, 15.4 M L1->L2 requests), L2 misses even UP 3.5 M -> 4.9 M, yet forward 286 -> 248 us, gather
 // 341 -> 320 us, decoder forward 24.7 -> 20.8 us: the gain is L2 bandwidth, not hit rate.  Run lengths 2..512 are
-// equivalent (254-260 us), 1 (adjacent tiles on different XCDs) gives 278, >= 2048 no rotation in practice; giving
+// equivalent in time (242-260 us; longer runs re-fetch fewer halo rows across XCDs: HBM reads 540 MB at 64, 418 MB at
+// 256, 356 MB without rotation -- but the bench step was 1.5 % slower with 256 or a launch-size dependent length),
+// 1 (adjacent tiles on different XCDs) gives 278, >= 2048 no rotation in practice; giving
 // every XCD all 8 heads of a contiguous eighth of the tiles was as slow as no rotation.  A head-major copy of the
 // value map (N,M,S,D) brought nothing on top.  Speed only -- any bijection is correct.
 constexpr int kHeadRun = 64;
