@@ -129,3 +129,9 @@ def test_assigner_surface_and_registry():
     for meth in ("before_run", "before_train_iter", "after_train_iter", "momentum_update"):
         assert callable(getattr(h, meth))
     assert s.ema_momentum(0.999, 0, 0) == 0.0          # step 0 copies the student (warm_up=0)
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: make (incremental) for the HIP library and the oracle, import, ABI version."""
+    import __graft_entry__
+    __graft_entry__.build()
