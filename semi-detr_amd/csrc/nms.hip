@@ -150,26 +150,29 @@ __global__ __launch_bounds__(kClsThreads) void nms_class_kernel(const float *__r
     __shared__ unsigned long long keys[NP2];
     __shared__ float4 ob[NP2];       // class-offset boxes in score order
     __shared__ float4 kb[NP2];       // ... of the candidates kept so far
-    __shared__ int s_n, s_base;
+    __shared__ int s_base;
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    int mine = 0;
-#pragma unroll 8
-    for (int q = tid; q < NP2; q += kClsThreads) {
+    // candidates above the threshold, compacted to the front (one wavefront: ballot prefix), so that the sort only
+    // covers the next power of two >= n instead of all NP2 slots
+    int n = 0;
+#pragma unroll 4
+    for (int q0 = 0; q0 < NP2; q0 += kClsThreads) {
+        const int q = q0 + tid;
         unsigned long long key = 0;
         if (q < Q) {
             const float x = logits[((size_t)b * Q + q) * C + c];
-            if (sigmoidf_(x) > score_thr) {
+            if (sigmoidf_(x) > score_thr)
                 key = ((unsigned long long)orderable(x) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)q);
-                ++mine;
-            }
         }
-        keys[q] = key;
+        const unsigned long long mask = __ballot(key != 0);
+        if (key) keys[n + __popcll(mask & ((1ull << tid) - 1ull))] = key;
+        n += __popcll(mask);
+        if (q0 + kClsThreads >= Q) break;
     }
-    if (mine) atomicAdd(&s_n, mine);
-    bitonic_desc<kClsThreads>(keys, NP2);
-    const int n = s_n;
+    int n2 = kClsThreads;
+    while (n2 < n) n2 <<= 1;
+    for (int i = n + tid; i < n2; i += kClsThreads) keys[i] = 0;
+    bitonic_desc<kClsThreads>(keys, n2);
     if (n == 0) return;
     const float off = (float)c * (ws.maxc[b] + 1.0f);
     for (int i = tid; i < n; i += kClsThreads) {
