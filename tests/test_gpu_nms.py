@@ -62,6 +62,8 @@ def _random_batch(seed, B, Q, C, bias, quant=None, spread=2.0):
     ("ties", 3, 200, 12, -1.0, 4, 100),                  # many exactly equal logits: the tie rule
     ("tiny", 4, 3, 2, 0.0, None, 300),
     ("wide", 2, 1500, 3, -2.0, None, 300),               # Q > 1024: the 2048-slot sort
+    ("max_queries", 1, 2048, 2, 1.0, None, 2048),        # the size limits of the entry point
+    ("many_classes", 2, 100, 365, -3.0, None, 300),      # Objects365-sized class count
 ])
 def test_nms_batch_vs_oracle(name, B, Q, C, bias, quant, max_per_img):
     from semi_detr_amd import get_bboxes_for_pseudo_label

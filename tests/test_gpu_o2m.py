@@ -71,7 +71,7 @@ def test_o2m_batch_targets_match_reference_fixture_and_oracle():
 
 
 @pytest.mark.parametrize("Q,C,G,topk,alpha,beta", [(1500, 11, 9, 13, 1, 6), (64, 3, 5, 1, 1, 6), (300, 20, 12, 20, 0.5, 2.0),
-                                                   (200, 4, 3, 200, 1, 6)])
+                                                   (200, 4, 3, 200, 1, 6), (2048, 91, 300, 13, 1, 6), (900, 80, 1024, 13, 1, 6)])
 def test_o2m_random_vs_oracle(Q, C, G, topk, alpha, beta):
     from semi_detr_amd import O2MAssigner
     rng = np.random.default_rng(Q + G)
