@@ -557,7 +557,7 @@ def main():
             "group_gbs": {k: v["bytes"] * v["launches"] / (v["ms"] * 1e-3) / 1e9 for k, v in sorted(stats.items())
                           if v["bytes"]},
         }
-        if not args.no_micro:
+        if world == 1 and not args.no_micro:      # single-GPU extras; at N > 1 the other ranks would only wait
             out["microbench"] = microbench(dev)
             out["module_fused_prologue"] = module_bench(dev)
             out["warmup_stage"] = warmup_stage_bench(dev)
