@@ -442,6 +442,20 @@ def warmup_stage_bench(dev, iters=20):
     return res
 
 
+def kernel_symbols(group):
+    """Device kernels behind an event-timed group (names as rocprofv3 prints them, profiles/r01_bench_kernel_stats.txt)."""
+    if group.startswith("msda_fwd_enc"):
+        return ["msda_fwd_d32<1, 4, 408, LocAttnIO>"]
+    if group.startswith("msda_bwd_enc"):
+        return ["__amd_rocclr_fillBufferAligned", "msda_bwd_gather_d32<LocAttnIO, 16, 408>",
+                "msda_bwd_scatter_d32_win<LocAttnIO, 16, 16, 32, 32>"]
+    if group.startswith("msda_fwd_dec"):
+        return ["msda_fwd_d32<1|2|4, 4, 0, LocAttnIO>"]
+    if group.startswith("msda_bwd_dec"):
+        return ["__amd_rocclr_fillBufferAligned", "msda_bwd_d32<8|32, LocAttnIO>"]
+    return []
+
+
 def cpu_baseline():
     """The oracle (a C port of the reference arithmetic; the reference itself has no native CPU path --
     ms_deform_attn_cpu.cpp:26,39 only raises) timed on this box's host cores with OpenMP on a bounded sample:
@@ -547,7 +561,7 @@ def main():
                        "images_per_gpu": IMAGES_PER_GPU,
                        "parallelism": "dp%d image-sharded, grad all-reduce %d fp32 over RCCL" % (world, GRAD_ELEMS)
                        if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom_name, "kernel_symbols": kernel_symbols(dom_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
                          if traffic else None,
