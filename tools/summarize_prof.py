@@ -2,6 +2,7 @@
 """Condense rocprofv3 output directories into the small summaries kept under profiles/.
     python tools/summarize_prof.py stats  <dir with *_kernel_stats.csv>  > profiles/rNN_<name>_kernel_stats.txt
     python tools/summarize_prof.py pmc    <dir with *_counter_collection.csv> <COUNTER> > profiles/rNN_<name>_pmc.txt
+    python tools/summarize_prof.py bygrid <dir with *_kernel_trace.csv>  > profiles/rNN_<name>_kernel_by_grid.txt
 """
 import collections
 import csv
@@ -39,5 +40,23 @@ def pmc(d, counter):
             print(f"{k:70s} dispatches {len(v):4d}  avg {sum(v)/len(v):14.1f}  (= {sum(v)/len(v)*1024/1e6:9.1f} MB)")
 
 
+def bygrid(d):
+    """Per (kernel, grid size) averages from the kernel trace: separates the batch sizes one symbol is launched with,
+    so the averages can be held against bench.py's event-timed groups."""
+    f = max(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True), key=os.path.getmtime)
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        n = short(r["Kernel_Name"])
+        if n.startswith(("msda_", "nms_", "o2m_", "tal_", "lsap", "match_cost", "ema_", "pseudo_label", "transform_bboxes",
+                         "build_targets")):
+            agg[(n, int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]))].append(
+                (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print(f"# rocprofv3 --kernel-trace ; per (kernel, workgroups) ; source {f.split('gpurun_out/')[-1]}")
+    print(f"{'kernel':62s} {'workgroups':>12s} {'calls':>6s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s}")
+    for (n, gx, gy), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        if sum(v) > 200:
+            print(f"{n:62s} {str(gx) + 'x' + str(gy):>12s} {len(v):6d} {sum(v)/len(v):9.1f} {min(v):9.1f} {max(v):9.1f}")
+
+
 if __name__ == "__main__":
-    (stats if sys.argv[1] == "stats" else pmc)(*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "bygrid": bygrid}[sys.argv[1]](*sys.argv[2:])
