@@ -69,7 +69,9 @@ __host__ __device__ inline size_t lsap_bytes(int ncmax, int nrmax)
            align16((size_t)nrmax * 4) + align16((size_t)(nrmax + 1) * 4);
 }
 
-template <bool USE_LDS>
+// COST_LDS: the problem's cost block is copied into LDS (while it is checked for NaN / -inf) and the searches read
+// it from there -- every Dijkstra step otherwise waits for a dependent batch of global loads.
+template <bool USE_LDS, bool COST_LDS = false>
 __global__ __launch_bounds__(64) void lsap_kernel(
     const float *__restrict__ cost, const int32_t *__restrict__ gt_offsets,
     const int64_t *__restrict__ gt_labels, int Q, int ncmax, int nrmax, int64_t *__restrict__ match_row,
@@ -105,13 +107,15 @@ __global__ __launch_bounds__(64) void lsap_kernel(
     int *row4col = reinterpret_cast<int *>(base);       base += align16((size_t)ncmax * 4);
     int *remaining = reinterpret_cast<int *>(base);     base += align16((size_t)ncmax * 4);
     int *col4row = reinterpret_cast<int *>(base);       base += align16((size_t)nrmax * 4);
-    int *scanned = reinterpret_cast<int *>(base);
+    int *scanned = reinterpret_cast<int *>(base);       base += align16((size_t)(nrmax + 1) * 4);
+    float *cl = reinterpret_cast<float *>(base);        // COST_LDS only
 
     // scipy rejects NaN and -inf up front ("matrix contains invalid numeric entries")
     int bad = 0;
     for (int64_t k = lane; k < (int64_t)nr * nc; k += 64) {
         const float c = cb[k];
         if (c != c || c == -__builtin_huge_valf()) bad = 1;
+        if (COST_LDS) cl[k] = c;
     }
     if (__any(bad)) {
         if (lane == 0) status[b] = 2;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(64) void lsap_kernel(
         double min_val = 0.0;
         while (sink == -1) {
             const double ui = u[i];
-            const float *crow = cb + (int64_t)i * si;
+            const float *crow = (COST_LDS ? cl : cb) + (int64_t)i * si;
             Best best = {kInf, 0x7fffffff, -1};
             for (int it = lane; it < num_rem; it += 64) {
                 const int j = remaining[it];
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(64) void lsap_kernel(
 }
 
 constexpr size_t kLdsLimit = 64 * 1024;
+constexpr size_t kLdsBig = 150 * 1024;      // with the cost block; one problem per CU then, fine for a latency-bound solver
 
 // Training targets from the assignment, all problems in one launch:
 // dino_detr_ssod_head.py:1170-1205 / dino_detr_head.py:937-980 with PseudoSampler
@@ -263,7 +268,15 @@ extern "C" int semidetr_lsap_solve(void *stream, const float *cost, const int32_
     const int nrmax = num_query < max_gt ? num_query : max_gt;
     const size_t per = lsap_bytes(ncmax > 0 ? ncmax : 1, nrmax > 0 ? nrmax : 1);
     hipStream_t st = semidetr::as_stream(stream);
-    if (per <= kLdsLimit) {
+    const size_t cost_bytes = (size_t)max_gt * (size_t)num_query * sizeof(float);
+    if (per <= kLdsLimit && per + cost_bytes <= kLdsBig) {         // solver state AND the cost block in LDS
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsap_kernel<true, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBig);
+        if (e != hipSuccess) return semidetr::fail((int)e, "lsap: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((lsap_kernel<true, true>), dim3(num_problems), dim3(64), per + cost_bytes, st, cost, gt_offsets,
+                           gt_labels, num_query, ncmax, nrmax, match_row, match_col, assigned_gt_inds,
+                           assigned_labels, status, (char *)nullptr, (size_t)0);
+    } else if (per <= kLdsLimit) {
         hipLaunchKernelGGL(lsap_kernel<true>, dim3(num_problems), dim3(64), per, st, cost, gt_offsets,
                            gt_labels, num_query, ncmax, nrmax, match_row, match_col, assigned_gt_inds,
                            assigned_labels, status, (char *)nullptr, (size_t)0);
