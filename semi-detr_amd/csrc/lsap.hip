@@ -135,14 +135,34 @@ __global__ __launch_bounds__(64) void lsap_kernel(
             const double ui = u[i];
             const float *crow = (COST_LDS ? cl : cb) + (int64_t)i * si;
             Best best = {kInf, 0x7fffffff, -1};
-            for (int it = lane; it < num_rem; it += 64) {
-                const int j = remaining[it];
-                const double r = min_val + (double)crow[(int64_t)j * sj] - ui - v[j];
-                double s = spc[j];
-                if (r < s) { path[j] = i; spc[j] = r; s = r; }
-                const bool un = row4col[j] == -1;
-                if (s < best.low) { best.low = s; best.first = it; best.last_un = un ? it : -1; }
-                else if (s == best.low && un) best.last_un = it;
+            // four list positions per lane and trip: the list-indirected reads (remaining -> cost, v, spc, row4col)
+            // are independent across positions (distinct columns), so they are issued together instead of as
+            // four dependent chains; positions are still consumed in increasing order (the tie rule needs that)
+            for (int it0 = lane; it0 < num_rem; it0 += 256) {
+                int jj[4];
+                double cc[4], vv[4], ss[4];
+                int rr[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) jj[t] = it0 + 64 * t < num_rem ? remaining[it0 + 64 * t] : -1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int j = jj[t] < 0 ? 0 : jj[t];
+                    cc[t] = (double)crow[(int64_t)j * sj];
+                    vv[t] = v[j];
+                    ss[t] = spc[j];
+                    rr[t] = row4col[j];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (jj[t] < 0) break;
+                    const int it = it0 + 64 * t, j = jj[t];
+                    const double r = min_val + cc[t] - ui - vv[t];
+                    double s = ss[t];
+                    if (r < s) { path[j] = i; spc[j] = r; s = r; }
+                    const bool un = rr[t] == -1;
+                    if (s < best.low) { best.low = s; best.first = it; best.last_un = un ? it : -1; }
+                    else if (s == best.low && un) best.last_un = it;
+                }
             }
             best = wave_best(best);
             min_val = best.low;
