@@ -135,17 +135,19 @@ __device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, 
 
 // Workgroup -> (n, query tile, m).  Consecutive workgroups take consecutive heads, and the head of a given slot is
 // rotated every kHeadRun tiles.  Why: rows of one head are M*128 bytes apart, so with M == 8 all addresses one head
-// touches share bits [9:7].  Workgroups go round robin to the 8 XCDs, so "blockIdx % 8 == head" pins each XCD to
-// ONE such address class for the whole launch -- its L2 serves every request from a fraction of its channels.
-// With the rotation an XCD works on ~3 heads at any time (runs of adjacent tiles still share head and XCD, i.e.
-// their halo rows stay in one L2).  Measured at the encoder shape, bs 4 (rocprofv3 PMC): same L1 traffic and hit
-// rate (91 M accesses, 15.4 M L1->L2 requests), L2 misses even UP 3.5 M -> 4.9 M, yet forward 286 -> 248 us, gather
-// 341 -> 320 us, decoder forward 24.7 -> 20.8 us: the gain is L2 bandwidth, not hit rate.  Run lengths 2..512 are
-// equivalent in time (242-260 us; longer runs re-fetch fewer halo rows across XCDs: HBM reads 540 MB at 64, 418 MB at
-// 256, 356 MB without rotation -- but the bench step was 1.5 % slower with 256 or a launch-size dependent length),
-// 1 (adjacent tiles on different XCDs) gives 278, >= 2048 no rotation in practice; giving
-// every XCD all 8 heads of a contiguous eighth of the tiles was as slow as no rotation.  A head-major copy of the
-// value map (N,M,S,D) brought nothing on top.  Speed only -- any bijection is correct.
+// touches share bits [9:7]; workgroups go round robin to the 8 XCDs, so "blockIdx % 8 == head" pins each XCD to
+// ONE such address class for the whole launch.  Measured at the encoder shape, bs 4 (rocprofv3 PMC,
+// profiles/r01_msda_fwd_enc_mapping_pmc.txt): with the rotation the L1 traffic and L1 miss traffic are identical
+// (91 M accesses, 15.4 M L1->L2 requests), L2 misses go UP 3.5 M -> 4.9 M, yet forward 286 -> 248 us, gather
+// 341 -> 320 us, decoder forward 24.7 -> 20.8 us.  Run lengths 2..512 are equivalent in time (242-260 us; longer
+// runs re-fetch fewer halo rows across XCDs: HBM reads 540 MB at 64, 418 MB at 256, 356 MB without rotation -- but
+// the bench step was 1.5 % slower with 256 or a launch-size dependent length), 1 (adjacent tiles on different XCDs)
+// gives 278, 2048 gives 268, >= 8192 is no rotation in practice.  Since a run of 512 tiles (one head per XCD at any
+// instant, ~7 different heads per XCD over the launch) is as good as 64, what matters is that no XCD stays married
+// to one address class: the classes are evidently not equally fast from every XCD, every XCD has the same amount
+// of work, and the launch ends with the slowest one.  Giving every XCD all 8 heads of a contiguous eighth of the
+// tiles was as slow as no rotation (not understood); a head-major copy of the value map (N,M,S,D) brought nothing
+// on top.  Speed only -- any bijection is correct.
 constexpr int kHeadRun = 64;
 struct Tile {
     int n, q0, m;
