@@ -192,7 +192,11 @@ class Workload:
         self._timed(f"msda_bwd_{kind}_bs{n}_Lq{lq}", reps, msda_alg_bytes(n, lq, True), run)
 
     def _pseudo(self):
-        boxes, labels, scores = self.sda.teacher_pseudo_labels(self.t_logits, self.t_boxes, self.t_metas)
+        # queued behind the teacher's forward; the lists are only needed where the unsupervised loss matches them
+        self.pending = self.sda.teacher_pseudo_labels(self.t_logits, self.t_boxes, self.t_metas, wait=False)
+
+    def _pseudo_finish(self):
+        boxes, labels, scores = self.pending.result()
         self.sda.transform_bboxes(boxes, self.warp, [m["img_shape"] for m in self.t_metas])
 
     def _match(self, i):
@@ -211,6 +215,7 @@ class Workload:
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, q, 6)             # teacher simple_test
         self._timed("pseudo_label", 1, 0, self._pseudo)
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, q, 6)             # student no-grad forward
+        self._timed("pseudo_label", 0, 0, self._pseudo_finish)           # lists + weak->strong warp (compute_pseudo_label_loss)
         self._match(0)                                                   # inline matching, unsup_loss
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, qd, 6)            # student forward_dummy
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, qd, 6)            # teacher forward_dummy

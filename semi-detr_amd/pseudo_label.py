@@ -103,10 +103,38 @@ def get_bboxes_for_pseudo_label(cls_scores, bbox_preds, img_metas, score_thr=0.0
     return [(dets[b, :kept[b]], labels[b, :kept[b]]) for b in range(len(kept))]
 
 
+class PendingPseudoLabels:
+    """Pseudo labels whose list lengths are still on their way to the host (pinned buffer + event): the kernels
+    and the read-back are queued, ``result()`` waits for the event and slices.  Lets the step keep launching the
+    student's forward while the teacher's boxes are being decoded."""
+
+    def __init__(self, dets, labels, out_boxes, out_labels, out_scores, counts, max_per_img):
+        self._t = (dets, labels, out_boxes, out_labels, out_scores)
+        self._max = max_per_img
+        self._host = torch.empty(tuple(counts.shape), dtype=torch.int32).pin_memory()
+        self._host.copy_(counts, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._lists = None
+
+    def result(self, return_proposals=False):
+        if self._lists is None:
+            self._event.synchronize()
+            both = self._host.tolist()
+            dets, labels, ob, ol, os_ = self._t
+            m, B = self._max, dets.shape[0]
+            self._lists = ([ob[b * m:b * m + both[1][b]] for b in range(B)],
+                           [ol[b * m:b * m + both[1][b]] for b in range(B)],
+                           [os_[b * m:b * m + both[1][b]] for b in range(B)],
+                           [(dets[b, :both[0][b]], labels[b, :both[0][b]]) for b in range(B)])
+        return self._lists if return_proposals else self._lists[:3]
+
+
 def teacher_pseudo_labels(cls_scores, bbox_preds, img_metas, score_thr=0.01, iou_threshold=0.6, max_per_img=300,
-                          return_proposals=False):
+                          return_proposals=False, wait=True):
     """extract_teacher_info's box path end to end on the device (dino_detr_ssod.py:904-939): decoding + NMS, then
-    the mean+std filter, chained through device-side counts.  Returns (det_bboxes, det_labels, det_scores)."""
+    the mean+std filter, chained through device-side counts.  Returns (det_bboxes, det_labels, det_scores); with
+    ``wait=False`` a ``PendingPseudoLabels`` whose ``result()`` gives the same lists later (one event wait)."""
     dets, labels, count = _nms_batch(cls_scores, bbox_preds, img_metas, score_thr, iou_threshold, max_per_img)
     B, dev = dets.shape[0], dets.device
     offs = _lib_small([b * max_per_img for b in range(B + 1)], torch.int32, dev)
@@ -120,13 +148,9 @@ def teacher_pseudo_labels(cls_scores, bbox_preds, img_metas, score_thr=0.01, iou
             _lib.current_stream_ptr(), _p(dets), _p(labels), _p(offs), _p(count), B, _p(out_boxes), _p(out_labels),
             _p(out_scores), _p(None), _p(out_count), _p(out_thr))
     _lib.check(rc, "semidetr_pseudo_label_filter_f32")
-    both = torch.stack([count, out_count]).tolist()       # the one host sync
-    res = ([out_boxes[b * max_per_img:b * max_per_img + both[1][b]] for b in range(B)],
-           [out_labels[b * max_per_img:b * max_per_img + both[1][b]] for b in range(B)],
-           [out_scores[b * max_per_img:b * max_per_img + both[1][b]] for b in range(B)])
-    if return_proposals:
-        return res + ([(dets[b, :both[0][b]], labels[b, :both[0][b]]) for b in range(B)],)
-    return res
+    pending = PendingPseudoLabels(dets, labels, out_boxes, out_labels, out_scores, torch.stack([count, out_count]),
+                                  max_per_img)
+    return pending.result(return_proposals) if wait else pending
 
 
 def transform_bboxes(bbox, M, out_shape):

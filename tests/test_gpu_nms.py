@@ -94,6 +94,10 @@ def test_teacher_pseudo_labels_chain_equals_steps_and_oracle():
     metas = [_meta(h, w) for h, w in shapes]
     tl, tb = torch.from_numpy(logits).cuda(), torch.from_numpy(bbox).cuda()
     boxes, labels, scores, props = teacher_pseudo_labels(tl, tb, metas, return_proposals=True)
+    pending = teacher_pseudo_labels(tl, tb, metas, wait=False)          # read-back queued; result() waits for its event
+    later = pending.result(return_proposals=True)
+    assert all(torch.equal(a, b) for x, y in zip(later[:3], (boxes, labels, scores)) for a, b in zip(x, y))
+    assert pending.result() is not None and len(pending.result()) == 3
     sep = get_bboxes_for_pseudo_label(tl, tb, metas)
     b2, l2, s2 = filter_pseudo_labels([p[0] for p in sep], [p[1] for p in sep])
     for b in range(5):
