@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Randomised sweep of the fused MSDeformAttn prologue/epilogue (RawIO kernels) against the op-by-op path on the GPU
+(same sampling kernels behind the reference contract): output and all four gradients.
+    python tools/stress_fused.py --cases 200 --seed 0"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    from semi_detr_amd import MSDeformAttnFunction, MSDeformAttnFusedFunction
+    rng = np.random.default_rng(a.seed)
+    g = torch.Generator(device="cuda").manual_seed(a.seed)
+    worst, bad = {}, []
+    for case in range(a.cases):
+        L = int(rng.integers(1, 6))
+        shapes = sorted([(int(rng.integers(1, 30)), int(rng.integers(1, 40))) for _ in range(L)], key=lambda s: -s[0] * s[1])
+        M, P, N = int(rng.choice([1, 2, 4, 8])), int(rng.choice([1, 2, 4, 4, 3])), int(rng.integers(1, 3))
+        S = sum(h * w for h, w in shapes)
+        enc = rng.random() < 0.5
+        Lq = S if enc else int(rng.integers(1, 150))
+        ref_dim = int(rng.choice([2, 4]))
+        tsh = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
+        tls = torch.cat([tsh.new_zeros(1), (tsh[:, 0] * tsh[:, 1]).cumsum(0)[:-1]])
+        def rnd(*s):
+            return torch.rand(*s, generator=g, device="cuda")
+        value = (rnd(N, S, M, 32) - 0.3)
+        ref = rnd(N, Lq, L, ref_dim)
+        if ref_dim == 4:
+            ref[..., 2:] = ref[..., 2:] * 0.3 + 0.02
+        off = (rnd(N, Lq, M, L, P, 2) - 0.5) * (6.0 if ref_dim == 2 else 3.0)
+        logits = (rnd(N, Lq, M, L * P) - 0.5) * 6
+        gout = rnd(N, Lq, M * 32) - 0.5
+        res = []
+        for fused in (True, False):
+            v, r, o, lg = (t.clone().requires_grad_(True) for t in (value, ref, off, logits))
+            if fused:
+                out = MSDeformAttnFusedFunction.apply(v, tsh, tls, r, o, lg)
+            else:
+                w = torch.softmax(lg, -1).view(N, Lq, M, L, P)
+                if ref_dim == 2:
+                    norm = torch.stack([tsh[:, 1], tsh[:, 0]], -1)
+                    loc = r[:, :, None, :, None, :] + o / norm[None, None, None, :, None, :]
+                else:
+                    loc = r[:, :, None, :, None, :2] + o / P * r[:, :, None, :, None, 2:] * 0.5
+                out = MSDeformAttnFunction.apply(v, tsh, tls, loc.contiguous(), w.contiguous(), 64)
+            out.backward(gout)
+            res.append([out.detach(), v.grad, o.grad, lg.grad, r.grad])
+        for name, x, y in zip(("out", "gvalue", "goff", "glogit", "gref"), *res):
+            e = float((x - y).abs().max() / max(1.0, float(y.abs().max())))
+            worst[name] = max(worst.get(name, 0.0), e)
+            if e > (1e-5 if name == "out" else 3e-4):
+                bad.append((case, shapes, N, M, P, Lq, enc, ref_dim, name, e))
+    print("cases", a.cases, "worst", worst)
+    for b in bad[:10]:
+        print("BEYOND TOLERANCE:", b)
+    print("bad", len(bad))
+
+
+if __name__ == "__main__":
+    main()
