@@ -618,8 +618,14 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
     const int slot = (b / M) % tiles_bound, n = (b / M) / tiles_bound;
     const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
 
-    for (int tile = slot;; tile += tiles_bound) {
-        const Patch pt = find_patch<TH, TW>(tile, shapes, starts, L);
+    // Patches are taken in REVERSE enumeration order: the coarse levels' patches come first.  They are the slow ones
+    // (their footprint on the fine levels exceeds the window, so many of their corners go through the miss list),
+    // and a launch is only a few waves of workgroups deep -- the slow ones must not be the last to start.
+    int total_tiles = 0;
+    for (int l = 0; l < L; ++l)
+        total_tiles += (((int)shapes[2 * l] + TH - 1) / TH) * (((int)shapes[2 * l + 1] + TW - 1) / TW);
+    for (int tile_f = slot; tile_f < total_tiles; tile_f += tiles_bound) {
+        const Patch pt = find_patch<TH, TW>(total_tiles - 1 - tile_f, shapes, starts, L);
         if (pt.Hq == 0) break;
         // this thread's samples = (query i, point p) of the patch, sample index tid + sp * 512
         int qs[SPT];
