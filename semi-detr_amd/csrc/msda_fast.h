@@ -144,8 +144,9 @@ __device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, 
 // the bench step was 1.5 % slower with 256 or a launch-size dependent length), 1 (adjacent tiles on different XCDs)
 // gives 278, 2048 gives 268, >= 8192 is no rotation in practice.  Since a run of 512 tiles (one head per XCD at any
 // instant, ~7 different heads per XCD over the launch) is as good as 64, what matters is that no XCD stays married
-// to one address class: the classes are evidently not equally fast from every XCD, every XCD has the same amount
-// of work, and the launch ends with the slowest one.  Giving every XCD all 8 heads of a contiguous eighth of the
+// to one address class: the classes are not equally fast from every XCD once the accesses leave the L2
+// (tools/xcd_class_probe.hip: up to 1.5x between (XCD, class) pairs), every XCD has the same amount of work, and the
+// launch ends with the slowest one.  Giving every XCD all 8 heads of a contiguous eighth of the
 // tiles was as slow as no rotation (not understood); a head-major copy of the value map (N,M,S,D) brought nothing
 // on top.  Speed only -- any bijection is correct.
 constexpr int kHeadRun = 64;
