@@ -145,3 +145,29 @@ def test_pseudo_label_filter_large_ragged():
         assert np.array_equal(b.cpu().numpy(), p[keep, :4])
         assert np.array_equal(la.cpu().numpy(), l[keep])
         assert np.array_equal(s.cpu().numpy(), p[keep, 4])
+
+
+def test_rccl_backend_initialises_and_reduces_on_this_gpu():
+    """One-rank process group on backend 'nccl' (= RCCL on ROCm), run in a child process: the communicator binds to
+    the GPU, an all-reduce and a barrier complete.  (The N > 1 collective path itself is covered with gloo in
+    tests/test_dp_gloo.py; this checks that the RCCL side is usable on the box.)"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "import sys; sys.path.insert(0, os.getcwd())\n"
+        "from semi_detr_amd import dp\n"
+        "g = torch.arange(1000, dtype=torch.float32, device='cuda')\n"
+        "w = dist.all_reduce(g, async_op=True); w.wait(); dist.barrier()\n"
+        "r = dp.GradAllReducer(g, bucket_bytes=1024); r.start(); r.launch_ready(0.5); r.finish()\n"
+        "s = dp.ScalarReducer(torch.device('cuda', 0)); s.add(3.0); s.add(torch.tensor(5.0, device='cuda'))\n"
+        "assert [float(v) for v in s.reduce_mean()] == [3.0, 5.0]\n"
+        "assert float(g[999]) == 999.0\n"
+        "dist.destroy_process_group(); print('rccl ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, out.stderr[-2000:]
