@@ -226,6 +226,77 @@ def gen_module(modl, func):
     np.savez_compressed(os.path.join(OUT, "msda_module.npz"), **d)
 
 
+MODULE_D32_LEVELS = [(8, 12), (4, 6), (2, 3), (1, 2)]
+MODULE_D32_CASES = (("enc_ref2", 2, False, True), ("enc_ref2_mask", 2, True, True),
+                    ("dec_ref4", 4, False, False), ("dec_ref4_mask", 4, True, False))
+
+
+def module_d32_inputs(name, refdim, use_mask, encoder, seed=77):
+    """Weights + inputs of the DINO-configuration module fixture (d_model 256, 8 heads x 32 channels, 4 levels x 4
+    points, fp32), regenerated from a seed on both sides (tests/conftest.py repeats exactly these calls).  Encoder
+    cases: query i IS pixel i (Lq == S, 2-d reference points = pixel centres x a valid ratio); decoder cases: 37
+    queries with 4-d reference boxes."""
+    g = torch.Generator().manual_seed(seed + sum(map(ord, name)))
+    levels = MODULE_D32_LEVELS
+    S = sum(h * w for h, w in levels)
+    N, d, M, L, P = 2, 256, 8, 4, 4
+    Lq = S if encoder else 37
+
+    def rn(*s, std=1.0):
+        return torch.randn(*s, generator=g) * std
+
+    th = torch.arange(M, dtype=torch.float32) * (2.0 * np.pi / M)
+    grid = torch.stack([th.cos(), th.sin()], -1)
+    grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(M, 1, 1, 2).repeat(1, L, P, 1)
+    grid = grid * torch.arange(1, P + 1, dtype=torch.float32).view(1, 1, -1, 1)
+    sd = {"sampling_offsets.weight": rn(M * L * P * 2, d, std=0.02),
+          "sampling_offsets.bias": grid.reshape(-1) + rn(M * L * P * 2, std=0.1),
+          "attention_weights.weight": rn(M * L * P, d, std=0.1), "attention_weights.bias": rn(M * L * P, std=0.3),
+          "value_proj.weight": rn(d, d, std=0.06), "value_proj.bias": rn(d, std=0.1),
+          "output_proj.weight": rn(d, d, std=0.06), "output_proj.bias": rn(d, std=0.1)}
+    query, src = rn(N, Lq, d), rn(N, S, d)
+    if encoder:       # transformer.py:675-691 -- pixel centres, scaled by per-image valid ratios
+        ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w,
+                                                    indexing="ij"), -1).flip(-1).reshape(-1, 2) for h, w in levels])
+        vr = torch.rand(N, 1, L, 2, generator=g) * 0.3 + 0.7
+        ref = (ref.view(1, S, 1, 2) * vr).contiguous()
+    else:
+        ref = torch.rand(N, Lq, L, 4, generator=g)
+        ref[..., 2:] = ref[..., 2:] * 0.3 + 0.05
+    mask = (torch.rand(N, S, generator=g) < 0.2) if use_mask else None
+    gout = rn(N, Lq, d)
+    return levels, sd, query, src, ref.float(), mask, gout
+
+
+def gen_module_d32(modl, func):
+    """Pins the path the product takes BY DEFAULT (MSDeformAttn.fuse_prologue: fp32, 32 channels per head) to the
+    reference's own module (modules/ms_deform_attn.py:78-126) + torch.autograd: output and the gradients w.r.t.
+    query, input_flatten, reference_points and all eight parameters.  Large arrays are stored as flat[::5]."""
+    func.MSDeformAttnFunction.apply = staticmethod(
+        lambda v, sh, ls, loc, a, step: func.ms_deform_attn_core_pytorch(v, sh, loc, a))
+    d = {}
+    for name, refdim, use_mask, encoder in MODULE_D32_CASES:
+        levels, sd, query, src, ref, mask, gout = module_d32_inputs(name, refdim, use_mask, encoder)
+        m = modl.MSDeformAttn(d_model=256, n_levels=4, n_heads=8, n_points=4)
+        m.load_state_dict(sd, strict=True)
+        sh = torch.as_tensor(levels, dtype=torch.long)
+        ls = torch.as_tensor(level_start(levels))
+        q, s_, r = [t.clone().requires_grad_(True) for t in (query, src, ref)]
+        out = m(q, r, s_, sh, ls, mask)
+        out.backward(gout)
+
+        def pack(t):
+            a = t.detach().numpy().reshape(-1)
+            return a if a.size <= 4096 else a[::5].copy()
+        d[f"{name}.out"] = out.detach().numpy()
+        d[f"{name}.g_query"], d[f"{name}.g_src"], d[f"{name}.g_ref"] = pack(q.grad), pack(s_.grad), pack(r.grad)
+        for k, p in m.named_parameters():
+            d[f"{name}.g_{k}"] = pack(p.grad)
+        d[f"{name}.input_checksum"] = np.asarray([t.double().sum().item() for t in (query, src, ref, gout)]
+                                                 + [sd[k].double().sum().item() for k in sorted(sd)])
+    np.savez_compressed(os.path.join(OUT, "msda_module_d32.npz"), **d)
+
+
 def ref_cost(mc, tr, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_w, img_h):
     """hungarian_assigner.py:115-129 with the DINO config weights (dino_detr_r50_8x2_12e_coco.py:41-44)."""
     cls_c = mc.FocalLossCost(weight=2.0)
@@ -627,6 +698,7 @@ def main():
     gen_msda(func)
     gen_msda_full(func)
     gen_module(modl, func)
+    gen_module_d32(modl, func)
     gen_cost(mc, tr)
     gen_lsap()
     gen_ema()

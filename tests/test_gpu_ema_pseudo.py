@@ -28,6 +28,26 @@ def test_ema_matches_torch_fixture_and_oracle(golden_ema):
             assert _ulp(got, z[f"m{mi}.t{si}.out"]) <= 1      # torch CPU: mul_ then add_(alpha)
 
 
+def test_ema_vs_torch_on_the_same_gpu():
+    """What the reference executes (mean_teacher.py:60-64) is `tgt.mul_(m).add_(src, alpha=1-m)` by torch ON THE GPU;
+    compare with exactly that on this device: many tensor sizes, several momenta (incl. the warm-up values 0 and 0.5).
+    torch's GPU add_(alpha) is one fma on the rounded product -- the same two roundings as ema.hip -- so the bar is
+    bit equality, reported as ulps if it ever differs."""
+    from semi_detr_amd import ema_update_
+    torch.manual_seed(7)
+    sizes = [1, 7, 64, 255, 4096, 8191, 8193, 65537, 1 << 20, 2359296]
+    for mom in (0.0, 0.5, 0.9, 0.999, 0.9996, 1.0):
+        ts = [torch.randn(n).cuda() * 3 for n in sizes]
+        ss = [torch.randn(n).cuda() * 3 for n in sizes]
+        want = [t.clone() for t in ts]
+        for w, s in zip(want, ss):
+            w.mul_(mom).add_(s, alpha=1 - mom)
+        ema_update_(ts, ss, mom)
+        torch.cuda.synchronize()
+        for t, w in zip(ts, want):
+            assert _ulp(t.cpu().numpy(), w.cpu().numpy()) <= 1, (mom, t.numel())
+
+
 def test_ema_large_unaligned_and_flat():
     from semi_detr_amd import ema_update_, ema_update_flat_
     torch.manual_seed(1)

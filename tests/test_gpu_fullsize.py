@@ -1,0 +1,140 @@
+"""GPU parity at the sizes bench.py actually times ("shapes the bench times but no test checks"):
+
+  * encoder self-attention at bs 4 (N=4, Lq = S = 22 223: 28 288-workgroup patch forward, patch gather, destination-
+    owned / windowed scatter with head rotation across 4 images) -- the reference contract (LocAttnIO) AND the fused
+    prologue/epilogue (RawIO) -- against the CPU oracle, every element;
+  * the five-level full-size shape (S = 22 300, Lq = 900, bs 2);
+  * decoder size at bs 4 with de-noising padding (Lq = 1100).
+
+The oracle (plain C restatement pinned to the reference's Python by tests/golden) takes a few seconds per case here.
+grad_value is compared element by element (no sub-sampling), with an absolute bar scaled by its magnitude because the
+fp32 atomics make its summation order run-dependent (as in the reference).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from test_gpu_fused import _prologue_np
+
+pytestmark = pytest.mark.gpu
+
+LEVELS = [(100, 167), (50, 84), (25, 42), (13, 21)]
+M, D, P = 8, 32, 4
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _starts(tsh):
+    return torch.cat([tsh.new_zeros(1), (tsh[:, 0] * tsh[:, 1]).cumsum(0)[:-1]])
+
+
+def _pixel_centres(levels):
+    return np.concatenate([np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1)
+                           .reshape(-1, 2) for h, w in levels]).astype(np.float32)          # (S, 2) x, y
+
+
+def _check(out, gv, o_out, o_gv):
+    np.testing.assert_allclose(out, o_out, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(gv, o_gv, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gv).max())))
+
+
+@pytest.fixture(autouse=True)
+def _auto_variant():
+    import semi_detr_amd
+    semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, 0)
+    yield
+    semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, 0)
+
+
+def _encoder_case(N, levels, sigma_px, seed):
+    rng = np.random.default_rng(seed)
+    shp = np.asarray(levels, np.int64)
+    L = len(levels)
+    S = int((shp[:, 0] * shp[:, 1]).sum())
+    ref = np.broadcast_to(_pixel_centres(levels)[None, :, None, :], (N, S, L, 2)).copy()
+    off = (rng.standard_normal((N, S, M, L, P, 2)) * sigma_px).astype(np.float32)             # in pixels of the level
+    logits = (rng.standard_normal((N, S, M, L * P)) * 2).astype(np.float32)
+    value = (rng.random((N, S, M, D)) * 0.01).astype(np.float32)
+    gout = rng.random((N, S, M * D)).astype(np.float32)
+    return value, shp, ref, off, logits, gout
+
+
+@pytest.mark.parametrize("io", ["locattn", "raw"])
+def test_encoder_bs4_full_size_vs_oracle(io):
+    """N=4, Lq=S=22223, locations = pixel centre + N(0, (2 px)^2) per level: forward, grad_value, and the two small
+    gradients (through the fused epilogue for `raw`) element by element against the oracle."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd  # noqa: F401
+    N = 4
+    value, shp, ref, off, logits, gout = _encoder_case(N, LEVELS, 2.0, 11)
+    loc, attn = _prologue_np(ref, off, logits, shp, P)
+    o_out = oracle.msda_forward(value, shp, loc, attn)
+    o_gv, o_gl, o_ga = oracle.msda_backward(value, shp, loc, attn, gout)
+    tsh = _t(shp)
+    tls = _starts(tsh)
+    if io == "locattn":
+        out = MSDA.ms_deform_attn_forward(_t(value), tsh, tls, _t(loc), _t(attn), 64)
+        gv, gl, ga = MSDA.ms_deform_attn_backward(_t(value), tsh, tls, _t(loc), _t(attn), _t(gout), 64)
+        torch.cuda.synchronize()
+        _check(out.cpu().numpy(), gv.cpu().numpy(), o_out, o_gv)
+        np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(gl.cpu().numpy(), o_gl, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gl).max())))
+        return
+    out = MSDA.ms_deform_attn_fused_forward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits))
+    gv, goff, glog = MSDA.ms_deform_attn_fused_backward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits), _t(gout))
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), gv.cpu().numpy(), o_out, o_gv)
+    # epilogue restated on the oracle's gradients (ms_deform_attn.py:101-105 differentiated)
+    norm = np.stack([shp[:, 1], shp[:, 0]], -1).astype(np.float64)[None, None, None, :, None, :]
+    want_off = (o_gl.astype(np.float64) / norm).astype(np.float32)
+    a64, g64 = attn.astype(np.float64).reshape(N, -1, M, 16), o_ga.astype(np.float64).reshape(N, -1, M, 16)
+    want_log = (a64 * (g64 - (a64 * g64).sum(-1, keepdims=True))).astype(np.float32)
+    np.testing.assert_allclose(goff.cpu().numpy(), want_off, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want_off).max())))
+    np.testing.assert_allclose(glog.cpu().numpy(), want_log, rtol=0, atol=2e-5)
+
+
+def test_encoder_bs4_wide_offsets_vs_oracle():
+    """Same size, but offsets far beyond any window / reach margin (sigma 12 px, some samples outside the map):
+    exercises the out-of-reach (atomic) branch of the scatter on every level.  One image pair is enough."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd  # noqa: F401
+    N = 2
+    value, shp, ref, off, logits, gout = _encoder_case(N, LEVELS, 12.0, 12)
+    loc, attn = _prologue_np(ref, off, logits, shp, P)
+    o_gv, o_gl, o_ga = oracle.msda_backward(value, shp, loc, attn, gout)
+    tsh = _t(shp)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(_t(value), tsh, _starts(tsh), _t(loc), _t(attn), _t(gout), 64)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(gv.cpu().numpy(), o_gv, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gv).max())))
+    np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("name,levels,N,Lq", [("five_level_bs2_Lq900", LEVELS + [(7, 11)], 2, 900),
+                                               ("decoder_bs4_Lq1100", LEVELS, 4, 1100)])
+def test_decoder_full_size_vs_oracle(name, levels, N, Lq):
+    """bench.py's `five_level_bs2_Lq900` secondary shape (S = 22 300) and the bs-4 decoder launch with de-noising
+    padding, uniform locations with a border band outside [0, 1] (zero padding at full size)."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd  # noqa: F401
+    rng = np.random.default_rng(len(name))
+    shp = np.asarray(levels, np.int64)
+    L = len(levels)
+    S = int((shp[:, 0] * shp[:, 1]).sum())
+    value = (rng.random((N, S, M, D)) * 0.01).astype(np.float32)
+    loc = (rng.random((N, Lq, M, L, P, 2)) * 1.1 - 0.05).astype(np.float32)
+    attn = rng.random((N, Lq, M, L, P)).astype(np.float32) + 1e-5
+    attn /= attn.sum((-1, -2), keepdims=True)
+    gout = rng.random((N, Lq, M * D)).astype(np.float32)
+    o_out = oracle.msda_forward(value, shp, loc, attn)
+    o_gv, o_gl, o_ga = oracle.msda_backward(value, shp, loc, attn, gout)
+    tsh = _t(shp)
+    tls = _starts(tsh)
+    out = MSDA.ms_deform_attn_forward(_t(value), tsh, tls, _t(loc), _t(attn), 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(_t(value), tsh, tls, _t(loc), _t(attn), _t(gout), 64)
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), gv.cpu().numpy(), o_out, o_gv)
+    np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(gl.cpu().numpy(), o_gl, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gl).max())))

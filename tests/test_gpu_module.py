@@ -60,3 +60,51 @@ def test_module_errors():
     with pytest.raises(ValueError, match="Last dim of reference_points must be 2 or 4"):
         m(torch.zeros(1, 1, 32).cuda(), torch.zeros(1, 1, 1, 3).cuda(), torch.zeros(1, 4, 32).cuda(), shapes,
           shapes.new_zeros(1))
+
+
+# ---------------------------------------------------------------------------------------------------
+# The path the product takes BY DEFAULT (fuse_prologue, fp32, 32 channels per head) against the reference's own
+# module + torch.autograd at d_model 256 / 8 heads / 4 levels / 4 points (oracle/gen_golden.py:gen_module_d32):
+# encoder-like (Lq == S, 2-d reference points) and decoder-like (4-d reference boxes), with / without padding mask.
+# ---------------------------------------------------------------------------------------------------
+def _pack(t):
+    a = t.detach().cpu().numpy().reshape(-1)
+    return a if a.size <= 4096 else a[::5]
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("case", ["enc_ref2", "enc_ref2_mask", "dec_ref4", "dec_ref4_mask"])
+def test_module_d32_matches_reference_module(case, fuse):
+    from oracle.gen_golden import MODULE_D32_CASES, module_d32_inputs
+    from semi_detr_amd import MSDeformAttn
+    import MultiScaleDeformableAttention as MSDA
+    from conftest import Golden
+    g = Golden("msda_module_d32.npz")[case]
+    name, refdim, use_mask, encoder = next(c for c in MODULE_D32_CASES if c[0] == case)
+    levels, sd, query, src, ref, mask, gout = module_d32_inputs(name, refdim, use_mask, encoder)
+    m = MSDeformAttn(256, 4, 8, 4)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    m.fuse_prologue = fuse
+    shapes = torch.as_tensor(levels, dtype=torch.long).cuda()
+    ls = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    q, s_, r = [t.cuda().requires_grad_(True) for t in (query, src, ref)]
+    calls = []
+    orig = MSDA.ms_deform_attn_fused_forward
+    MSDA.ms_deform_attn_fused_forward = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        out = m(q, r, s_, shapes, ls, mask.cuda() if mask is not None else None)
+    finally:
+        MSDA.ms_deform_attn_fused_forward = orig
+    assert bool(calls) == fuse, "the fused kernels must be what runs when fuse_prologue is set (and only then)"
+    out.backward(gout.cuda())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=2e-5)
+
+    def close(got, key, rel=2e-4):
+        want = g[key]
+        np.testing.assert_allclose(_pack(got), want, rtol=1e-3, atol=rel * np.abs(want).max(), err_msg=key)
+    close(q.grad, "g_query")
+    close(s_.grad, "g_src")
+    close(r.grad, "g_ref")
+    for k, p in m.named_parameters():
+        close(p.grad, "g_" + k)

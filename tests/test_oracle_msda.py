@@ -58,3 +58,16 @@ def test_oracle_full_microbench_shape_matches_reference():
     out = oracle.msda_forward(value, shapes, loc, attn)
     gv, gl, ga = oracle.msda_backward(value, shapes, loc, attn, gout)
     check_full_shape(out, gv, gl, ga, loc, golden)
+
+
+def test_module_d32_fixture_inputs_regenerate():
+    """tests/golden/msda_module_d32.npz stores only outputs; weights and inputs are regenerated from a seed by
+    oracle/gen_golden.py:module_d32_inputs.  Their checksums must match what the fixture was generated from."""
+    from conftest import Golden
+    from oracle.gen_golden import MODULE_D32_CASES, module_d32_inputs
+    g = Golden("msda_module_d32.npz")
+    for name, refdim, use_mask, encoder in MODULE_D32_CASES:
+        levels, sd, query, src, ref, mask, gout = module_d32_inputs(name, refdim, use_mask, encoder)
+        got = [t.double().sum().item() for t in (query, src, ref, gout)] + [sd[k].double().sum().item() for k in sorted(sd)]
+        np.testing.assert_allclose(got, g[name]["input_checksum"], rtol=1e-12)
+        assert g[name]["out"].shape == (2, query.shape[1], 256)
