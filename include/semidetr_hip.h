@@ -25,7 +25,7 @@ extern "C" {
 #define SEMIDETR_E_TOOLARGE (-2)    /* an index would overflow the 32-bit arithmetic used on device  */
 #define SEMIDETR_E_NODEVICE (-3)    /* no HIP device available                                        */
 
-#define SEMIDETR_ABI_VERSION 2
+#define SEMIDETR_ABI_VERSION 3
 
 int semidetr_abi_version(void);
 const char *semidetr_last_error(void);
@@ -51,11 +51,22 @@ const char *semidetr_last_error(void);
  * atomics, and writes every element of grad_sampling_loc / grad_attn_weight.
  * The whole batch is one launch (the reference's im2col_step chunking does not change results).
  * f32: fast path for channels == 32, generic path otherwise.  f64: generic path (gradcheck parity).
+ *
+ * `flags` (f32 entry points): SEMIDETR_MSDA_QUERIES_ARE_PIXELS tells the library that this is encoder
+ * self-attention -- num_query == spatial_size, query i IS pixel i of the pyramid, and spatial_shapes /
+ * level_start tile [0, spatial_size) exactly (level_start[l+1] == level_start[l] + H_l*W_l, sum H_l*W_l ==
+ * spatial_size).  The level table lives in device memory, so the library cannot verify this without a
+ * host synchronisation: the CALLER vouches for it (the Python / pybind layer checks it once per
+ * spatial_shapes tensor).  With the flag the forward / gather kernels take 2-D pixel patches and
+ * grad_value is produced by the destination-owned kernel; without it every query set takes the strip
+ * kernels, which make no assumption (the reference op has no such coupling).  Results are identical
+ * either way (up to fp32 summation order); the flag only selects faster kernels.
  * ------------------------------------------------------------------------------------------- */
+#define SEMIDETR_MSDA_QUERIES_ARE_PIXELS 1
 int semidetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                               const int64_t *level_start, const float *sampling_loc,
                               const float *attn_weight, int batch, int spatial_size, int num_heads,
-                              int channels, int num_levels, int num_query, int num_point, float *out);
+                              int channels, int num_levels, int num_query, int num_point, int flags, float *out);
 int semidetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,
                               const int64_t *level_start, const double *sampling_loc,
                               const double *attn_weight, int batch, int spatial_size, int num_heads,
@@ -64,7 +75,7 @@ int semidetr_msda_backward_f32(void *stream, const float *grad_out, const float 
                                const int64_t *spatial_shapes, const int64_t *level_start,
                                const float *sampling_loc, const float *attn_weight, int batch,
                                int spatial_size, int num_heads, int channels, int num_levels,
-                               int num_query, int num_point, float *grad_value,
+                               int num_query, int num_point, int flags, float *grad_value,
                                float *grad_sampling_loc, float *grad_attn_weight);
 int semidetr_msda_backward_f64(void *stream, const double *grad_out, const double *value,
                                const int64_t *spatial_shapes, const int64_t *level_start,
@@ -94,17 +105,18 @@ int semidetr_msda_fused_forward_f32(void *stream, const float *value, const int6
                                     const int64_t *level_start, const float *reference_points, int ref_dim,
                                     const float *sampling_offsets, const float *attn_logits, int batch,
                                     int spatial_size, int num_heads, int channels, int num_levels,
-                                    int num_query, int num_point, float *out);
+                                    int num_query, int num_point, int flags, float *out);
 int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const float *value,
                                      const int64_t *spatial_shapes, const int64_t *level_start,
                                      const float *reference_points, int ref_dim,
                                      const float *sampling_offsets, const float *attn_logits, int batch,
                                      int spatial_size, int num_heads, int channels, int num_levels,
-                                     int num_query, int num_point, float *grad_value,
+                                     int num_query, int num_point, int flags, float *grad_value,
                                      float *grad_sampling_offsets, float *grad_attn_logits);
 
-/* Tuning knob for benchmarking the f32 / channels==32 fast path: variant 0 = automatic choice,
- * >0 forces a kernel variant; process-wide, not thread-safe, tests leave it at 0. */
+/* TEST / TUNING ONLY -- not part of the re-entrant contract above: forces a kernel variant of the f32 /
+ * channels==32 fast path for every later call of the process (0 = automatic choice; codes in DESIGN.md 2.3b).
+ * Process-wide and not thread-safe; nothing in semi-detr_amd/ calls it, tests and tools/ reset it to (0, 0). */
 void semidetr_msda_set_variant(int fwd_variant, int bwd_variant);
 
 /* ---------------------------------------------------------------------------------------------

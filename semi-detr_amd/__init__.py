@@ -21,10 +21,11 @@ from .matcher import (AssignResult, BBoxL1Cost, FocalLossCost, HungarianAssigner
                       O2MAssigner, O2MAssignResult, linear_sum_assignment)
 from .losses import TaskAlignedFocalLoss, task_aligned_focal_loss  # noqa: E402,F401
 from .mean_teacher import MeanTeacher, ema_momentum, ema_update_, ema_update_flat_  # noqa: E402,F401
+from .targets import TargetAssigner, get_targets, get_targets_layers  # noqa: E402,F401
 from .pseudo_label import (filter_pseudo_labels, get_bboxes_for_pseudo_label, teacher_pseudo_labels,  # noqa: E402,F401
                            transform_bboxes)
 
 __all__ = ["MSDeformAttnFunction", "MSDeformAttnFusedFunction", "MSDeformAttn", "HungarianAssigner", "FocalLossCost", "BBoxL1Cost",
            "IoUCost", "AssignResult", "O2MAssigner", "O2MAssignResult", "TaskAlignedFocalLoss", "task_aligned_focal_loss", "linear_sum_assignment", "MeanTeacher", "ema_momentum", "ema_update_",
            "ema_update_flat_", "filter_pseudo_labels", "get_bboxes_for_pseudo_label", "teacher_pseudo_labels",
-           "transform_bboxes"]
+           "transform_bboxes", "TargetAssigner", "get_targets", "get_targets_layers"]

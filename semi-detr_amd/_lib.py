@@ -21,17 +21,19 @@ class CostParams(ctypes.Structure):
 
 _MSDA_FWD = [c_void_p] * 6 + [c_int] * 7 + [c_void_p]
 _MSDA_BWD = [c_void_p] * 7 + [c_int] * 7 + [c_void_p] * 3
+_MSDA_FWD_F32 = [c_void_p] * 6 + [c_int] * 8 + [c_void_p]           # f32 entry points carry `flags`
+_MSDA_BWD_F32 = [c_void_p] * 7 + [c_int] * 8 + [c_void_p] * 3
 
 # name -> (restype, argtypes); must list every function include/semidetr_hip.h declares
 SIGNATURES = {
     "semidetr_abi_version": (c_int, []),
     "semidetr_last_error": (ctypes.c_char_p, []),
-    "semidetr_msda_forward_f32": (c_int, _MSDA_FWD),
+    "semidetr_msda_forward_f32": (c_int, _MSDA_FWD_F32),
     "semidetr_msda_forward_f64": (c_int, _MSDA_FWD),
-    "semidetr_msda_backward_f32": (c_int, _MSDA_BWD),
+    "semidetr_msda_backward_f32": (c_int, _MSDA_BWD_F32),
     "semidetr_msda_backward_f64": (c_int, _MSDA_BWD),
-    "semidetr_msda_fused_forward_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 2 + [c_int] * 7 + [c_void_p]),
-    "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 2 + [c_int] * 7 + [c_void_p] * 3),
+    "semidetr_msda_fused_forward_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 2 + [c_int] * 8 + [c_void_p]),
+    "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 2 + [c_int] * 8 + [c_void_p] * 3),
     "semidetr_msda_set_variant": (None, [c_int, c_int]),
     "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
     "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),

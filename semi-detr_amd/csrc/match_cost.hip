@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void match_cost_kernel(
         const float4 gt = *reinterpret_cast<const float4 *>(gt_bboxes + (int64_t)(g0 + j) * 4);
         const int label = (int)gt_labels[g0 + j];
         // --- FocalLossCost
-        const float x = cls_row[label];
+        // a label outside [0, C) is an index error in the reference (match_cost.py:96); here it must neither read out
+        // of bounds nor pass silently: the cost becomes NaN, which the LSAP status word reports (ValueError)
+        const float x = (unsigned)label < (unsigned)C ? cls_row[label] : __builtin_nanf("");
         const float p = 1.0f / (1.0f + expf(-x));
         const float neg = -logf(1.0f - p + prm.eps) * (1.0f - prm.alpha) * pow_gamma(p, prm.gamma);
         const float pos = -logf(p + prm.eps) * prm.alpha * pow_gamma(1.0f - p, prm.gamma);

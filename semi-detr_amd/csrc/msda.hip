@@ -292,6 +292,10 @@ bool fast_ok(const void *a, const void *b, const void *c, int D, int L, int P)
     return D == kD && L <= kMaxLevels && (al & 15) == 0 && (int64_t)L * P <= 256;
 }
 
+// kOob + (head offset + lane offset) must stay out of range without wrapping: the in-row byte offset of a lane is
+// < num_heads * 128, so num_heads <= 32 keeps it below the 4096-byte guard band of kOob.
+bool heads_ok(int M) { return (int64_t)M * kD * 4 <= 4096; }
+
 // the fast-path kernels address one image's value slice with 32-bit BYTE offsets (buffer instructions)
 bool slice_ok(int S, int M) { return (int64_t)S * M * kD * 4 < (int64_t)0xFFFFF000u; }
 
@@ -310,8 +314,11 @@ int pick_split(int forced, int N, int Lq, int M)
 template <typename IO>
 int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spatial_shapes,
                         const int64_t *level_start, const IO &io, int N, int S, int M, int L, int Lq, int P,
-                        float *out)
+                        int flags, float *out)
 {
+    const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0;
+    SEMIDETR_REQUIRE(!pixels || Lq == S, SEMIDETR_E_BADARG,
+                     "msda_forward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const int split = pick_split(g_fwd_variant % 10, N, Lq, M);
     const int rpb = 32 / split;
     const int tiles = (Lq + rpb - 1) / rpb;
@@ -321,8 +328,8 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
 #define LAUNCH_FWD(SP, UN, PT, TILES)                                                                       \
     hipLaunchKernelGGL((msda_fwd_d32<SP, UN, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        lds, st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
-    if ((Lq == S && g_fwd_variant == 0) || g_fwd_variant == 408 || g_fwd_variant == 804 || g_fwd_variant == 216) {
-        SEMIDETR_REQUIRE(Lq == S, SEMIDETR_E_BADARG, "msda_forward: patch tiling needs num_query == spatial_size");
+    if ((pixels && g_fwd_variant == 0) || g_fwd_variant == 408 || g_fwd_variant == 804 || g_fwd_variant == 216) {
+        SEMIDETR_REQUIRE(pixels, SEMIDETR_E_BADARG, "msda_forward: patch tiling needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS");
         // grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges included)
         const int bound = (S + 31) / 32 * 5 / 4 + 4 * L;
         SEMIDETR_REQUIRE((int64_t)N * bound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
@@ -346,13 +353,16 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
 template <typename IO>
 int launch_fast_backward(hipStream_t st, const float *grad_out, const float *value, const int64_t *spatial_shapes,
                          const int64_t *level_start, const IO &io, int N, int S, int M, int L, int Lq, int P,
-                         float *grad_value)
+                         int flags, float *grad_value)
 {
+    const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0;
+    SEMIDETR_REQUIRE(!pixels || Lq == S, SEMIDETR_E_BADARG,
+                     "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * kD, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    if ((Lq == S && P == kPT && S < (1 << 24) && g_bwd_variant == 0) || g_bwd_variant == 64 || g_bwd_variant == 65 || g_bwd_variant == 66 || g_bwd_variant == 67) {
-        SEMIDETR_REQUIRE(Lq == S && P == kPT && S < (1 << 24), SEMIDETR_E_BADARG,
-                         "msda_backward: the windowed kernel needs num_query == spatial_size < 2^24 and num_point == 4");
+    if ((pixels && P == kPT && S < (1 << 24) && g_bwd_variant == 0) || g_bwd_variant == 64 || g_bwd_variant == 65 || g_bwd_variant == 66 || g_bwd_variant == 67) {
+        SEMIDETR_REQUIRE(pixels && P == kPT && S < (1 << 24), SEMIDETR_E_BADARG,
+                         "msda_backward: the windowed kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS, spatial_size < 2^24 and num_point == 4");
         {   // gather half: the two small gradients, streams like the forward
             const int gt = (Lq + 31) / 32;
             const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
@@ -416,11 +426,11 @@ extern "C" int semidetr_msda_forward_f32(void *stream, const float *value, const
                                          const int64_t *level_start, const float *sampling_loc,
                                          const float *attn_weight, int batch, int spatial_size,
                                          int num_heads, int channels, int num_levels, int num_query,
-                                         int num_point, float *out)
+                                         int num_point, int flags, float *out)
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query,
               P = num_point;
-    if (g_fwd_variant == 99 || !fast_ok(value, sampling_loc, out, D, L, P) || !slice_ok(S, M))
+    if (g_fwd_variant == 99 || !fast_ok(value, sampling_loc, out, D, L, P) || !slice_ok(S, M) || !heads_ok(M))
         return forward_impl<float>(stream, value, spatial_shapes, level_start, sampling_loc, attn_weight, N,
                                    S, M, D, L, Lq, P, out);
     if (int rc = check_common(value, spatial_shapes, level_start, sampling_loc, attn_weight, N, S, M, D, L,
@@ -429,19 +439,19 @@ extern "C" int semidetr_msda_forward_f32(void *stream, const float *value, const
     SEMIDETR_REQUIRE(out, SEMIDETR_E_BADARG, "msda_forward: null output");
     const LocAttnIO io = {sampling_loc, attn_weight, nullptr, nullptr};
     return launch_fast_forward(semidetr::as_stream(stream), value, spatial_shapes, level_start, io, N, S, M, L, Lq,
-                               P, out);
+                               P, flags, out);
 }
 
 extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, const float *value,
                                           const int64_t *spatial_shapes, const int64_t *level_start,
                                           const float *sampling_loc, const float *attn_weight, int batch,
                                           int spatial_size, int num_heads, int channels, int num_levels,
-                                          int num_query, int num_point, float *grad_value,
+                                          int num_query, int num_point, int flags, float *grad_value,
                                           float *grad_sampling_loc, float *grad_attn_weight)
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query,
               P = num_point;
-    if (g_bwd_variant == 99 || !fast_ok(value, sampling_loc, grad_out, D, L, P) || !slice_ok(S, M) ||
+    if (g_bwd_variant == 99 || !fast_ok(value, sampling_loc, grad_out, D, L, P) || !slice_ok(S, M) || !heads_ok(M) ||
         !fast_ok(grad_value, grad_sampling_loc, grad_attn_weight, D, L, P))
         return backward_impl<float>(stream, grad_out, value, spatial_shapes, level_start, sampling_loc,
                                     attn_weight, N, S, M, D, L, Lq, P, grad_value, grad_sampling_loc,
@@ -453,7 +463,7 @@ extern "C" int semidetr_msda_backward_f32(void *stream, const float *grad_out, c
                      "msda_backward: null pointer argument");
     const LocAttnIO io = {sampling_loc, attn_weight, grad_sampling_loc, grad_attn_weight};
     return launch_fast_backward(semidetr::as_stream(stream), grad_out, value, spatial_shapes, level_start, io, N, S,
-                                M, L, Lq, P, grad_value);
+                                M, L, Lq, P, flags, grad_value);
 }
 
 // ---- fused MSDeformAttn prologue / epilogue (fp32, channels == 32) --------------------------------------
@@ -464,8 +474,8 @@ static int check_fused(const void *value, const void *shapes, const void *starts
     SEMIDETR_REQUIRE(ref, SEMIDETR_E_BADARG, "msda_fused: null reference_points");
     SEMIDETR_REQUIRE(ref_dim == 2 || ref_dim == 4, SEMIDETR_E_BADARG,
                      "Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
-    SEMIDETR_REQUIRE(D == kD && L <= kMaxLevels && (int64_t)L * P <= 256 && slice_ok(S, M), SEMIDETR_E_BADARG,
-                     "msda_fused: only channels == 32 (got %d), <= %d levels, L*P <= 256, image slice < 4 GB", D, kMaxLevels);
+    SEMIDETR_REQUIRE(D == kD && L <= kMaxLevels && (int64_t)L * P <= 256 && slice_ok(S, M) && heads_ok(M), SEMIDETR_E_BADARG,
+                     "msda_fused: only channels == 32 (got %d), <= %d levels, L*P <= 256, <= 32 heads, image slice < 4 GB", D, kMaxLevels);
     SEMIDETR_REQUIRE((((uintptr_t)value | (uintptr_t)off) & 15) == 0, SEMIDETR_E_BADARG,
                      "msda_fused: value / sampling_offsets must be 16-byte aligned");
     return SEMIDETR_OK;
@@ -476,7 +486,7 @@ extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value,
                                                int ref_dim, const float *sampling_offsets,
                                                const float *attn_logits, int batch, int spatial_size,
                                                int num_heads, int channels, int num_levels, int num_query,
-                                               int num_point, float *out)
+                                               int num_point, int flags, float *out)
 {
     if (int rc = check_fused(value, spatial_shapes, level_start, reference_points, ref_dim, sampling_offsets,
                              attn_logits, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
@@ -485,7 +495,7 @@ extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value,
     const RawIO io = {reference_points, sampling_offsets, attn_logits, nullptr, nullptr, ref_dim, num_heads,
                       num_levels};
     return launch_fast_forward(semidetr::as_stream(stream), value, spatial_shapes, level_start, io, batch,
-                               spatial_size, num_heads, num_levels, num_query, num_point, out);
+                               spatial_size, num_heads, num_levels, num_query, num_point, flags, out);
 }
 
 extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const float *value,
@@ -493,7 +503,7 @@ extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_
                                                 const float *reference_points, int ref_dim,
                                                 const float *sampling_offsets, const float *attn_logits, int batch,
                                                 int spatial_size, int num_heads, int channels, int num_levels,
-                                                int num_query, int num_point, float *grad_value,
+                                                int num_query, int num_point, int flags, float *grad_value,
                                                 float *grad_sampling_offsets, float *grad_attn_logits)
 {
     if (int rc = check_fused(value, spatial_shapes, level_start, reference_points, ref_dim, sampling_offsets,
@@ -506,7 +516,7 @@ extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_
     const RawIO io = {reference_points, sampling_offsets, attn_logits, grad_sampling_offsets, grad_attn_logits,
                       ref_dim, num_heads, num_levels};
     return launch_fast_backward(semidetr::as_stream(stream), grad_out, value, spatial_shapes, level_start, io, batch,
-                                spatial_size, num_heads, num_levels, num_query, num_point, grad_value);
+                                spatial_size, num_heads, num_levels, num_query, num_point, flags, grad_value);
 }
 
 extern "C" int semidetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,

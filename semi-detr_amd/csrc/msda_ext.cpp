@@ -1,0 +1,279 @@
+// Compiled Python module `MultiScaleDeformableAttention` -- the drop-in for the reference's pybind module
+// (detr_od/models/utils/ops/src/vision.cpp:13-16, signatures of src/ms_deform_attn.h:20-61, host code of
+// src/cuda/ms_deform_attn_cuda.cu:20-153): same two entry points, same argument order, same precondition errors
+// (AT_ASSERTM -> RuntimeError), outputs freshly allocated on the inputs' device, launches on the CURRENT stream, no
+// synchronisation.  It holds no kernels: it validates at::Tensors and calls the C ABI of libsemidetr_hip.so
+// (include/semidetr_hip.h), which is where the hand-written gfx950 code lives.  Host-only C++ (g++), built by
+// csrc/Makefile; a ctypes call of the same ABI cost ~16 us per forward against a 4.7 us kernel (BENCH_r01), this
+// path costs the launch plus ~2 us.
+//
+// Besides the reference's two functions it exports the fused MSDeformAttn prologue/epilogue pair (SURVEY.md
+// section 8(f) row 1) and `pyramid_check`, the cached test behind SEMIDETR_MSDA_QUERIES_ARE_PIXELS.
+#include <torch/extension.h>
+
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <mutex>
+#include <vector>
+
+#include "semidetr_hip.h"
+
+namespace {
+
+void check_rc(int rc, const char *what)
+{
+    TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", semidetr_last_error());
+}
+
+const char *scalar_name(at::ScalarType t) { return c10::toString(t); }
+
+// ms_deform_attn.h:27-38 (CPU tensors only raise) and ms_deform_attn_cuda.cu:28-38 / :93-105
+void check_tensor(const at::Tensor &t, const at::Tensor &value, const char *name)
+{
+    TORCH_CHECK(t.is_contiguous(), name, " tensor has to be contiguous");
+    TORCH_CHECK(t.is_cuda(), name, " must be a CUDA tensor");
+    TORCH_CHECK(t.device() == value.device(), name, " must be on the same device as value");
+}
+
+struct Dims {
+    int N, S, M, D, L, Lq, P;
+};
+
+Dims op_dims(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &starts, const at::Tensor &loc,
+             const at::Tensor &attn, int64_t im2col_step, const char *what)
+{
+    TORCH_CHECK(value.is_cuda(), "Not implemented on the CPU");
+    check_tensor(value, value, "value");
+    check_tensor(shapes, value, "spatial_shapes");
+    check_tensor(starts, value, "level_start_index");
+    check_tensor(loc, value, "sampling_loc");
+    check_tensor(attn, value, "attn_weight");
+    TORCH_CHECK(value.dim() == 4 && loc.dim() == 6 && attn.dim() == 5, what,
+                ": expected value (N,S,M,D), sampling_loc (N,Lq,M,L,P,2), attn_weight (N,Lq,M,L,P)");
+    Dims d;
+    d.N = (int)value.size(0); d.S = (int)value.size(1); d.M = (int)value.size(2); d.D = (int)value.size(3);
+    d.L = (int)shapes.size(0); d.Lq = (int)loc.size(1); d.P = (int)loc.size(4);
+    const int64_t step = std::min<int64_t>(d.N, im2col_step);           // ms_deform_attn_cuda.cu:50-52
+    TORCH_CHECK(step > 0 && d.N % step == 0, "batch(", d.N, ") must divide im2col_step(", step, ")");
+    // the reference reads .data<int64_t>() of both index tensors -> anything but int64 raises
+    TORCH_CHECK(shapes.scalar_type() == at::kLong, "expected scalar type Long for spatial_shapes");
+    TORCH_CHECK(starts.scalar_type() == at::kLong, "expected scalar type Long for level_start_index");
+    TORCH_CHECK(value.scalar_type() == at::kFloat || value.scalar_type() == at::kDouble, "\"", what,
+                "\" not implemented for '", scalar_name(value.scalar_type()), "'");
+    TORCH_CHECK(loc.scalar_type() == value.scalar_type() && attn.scalar_type() == value.scalar_type(), what,
+                ": value, sampling_loc and attn_weight must share one dtype");
+    TORCH_CHECK(loc.size(0) == d.N && loc.size(2) == d.M && loc.size(3) == d.L && loc.size(5) == 2 &&
+                    attn.size(0) == d.N && attn.size(1) == d.Lq && attn.size(2) == d.M && attn.size(3) == d.L &&
+                    attn.size(4) == d.P && starts.numel() == d.L && shapes.dim() == 2 && shapes.size(1) == 2,
+                what, ": inconsistent tensor shapes");
+    return d;
+}
+
+// ---- is the level table an exact tiling of [0, S)?  The answer needs the table on the host (one blocking copy), so
+// it is cached per (spatial_shapes, level_start_index) tensor pair and version: a training step passes the same two
+// tensors to all twelve layers, so this is at most one synchronisation per step where the reference's module has one
+// per layer call (`assert (...).sum() == Len_in`, modules/ms_deform_attn.py:90).
+struct PyramidEntry {
+    c10::weak_intrusive_ptr<c10::TensorImpl> shapes, starts;
+    uint32_t v_shapes, v_starts;
+    int64_t S;
+    int result;
+};
+std::mutex g_pyr_mutex;
+std::vector<PyramidEntry> g_pyr_cache;
+
+// bit 0: sum(H*W) == S (the reference's assert); bit 1: level_start tiles [0, S) contiguously
+int pyramid_check(const at::Tensor &shapes, const at::Tensor &starts, int64_t S)
+{
+    auto *is = shapes.unsafeGetTensorImpl();
+    auto *it = starts.unsafeGetTensorImpl();
+    {
+        std::lock_guard<std::mutex> lock(g_pyr_mutex);
+        for (auto &e : g_pyr_cache) {
+            if (e.S != S || e.shapes._unsafe_get_target() != is || e.starts._unsafe_get_target() != it) continue;
+            auto a = e.shapes.lock();      // expired (address reused by a new tensor) -> nullptr
+            auto b = e.starts.lock();
+            if (a && b && e.v_shapes == is->version_counter().current_version() &&
+                e.v_starts == it->version_counter().current_version())
+                return e.result;
+        }
+    }
+    TORCH_CHECK(shapes.scalar_type() == at::kLong && starts.scalar_type() == at::kLong && shapes.dim() == 2 &&
+                    shapes.size(1) == 2 && starts.numel() == shapes.size(0),
+                "pyramid_check: expected spatial_shapes (L,2) and level_start_index (L,) of dtype int64");
+    const at::Tensor hs = shapes.to(at::kCPU).contiguous(), hl = starts.to(at::kCPU).contiguous();
+    const int64_t *ps = hs.data_ptr<int64_t>(), *pl = hl.data_ptr<int64_t>();
+    int64_t sum = 0;
+    bool tiles = true;
+    for (int64_t l = 0; l < hs.size(0); ++l) {
+        tiles = tiles && pl[l] == sum && ps[2 * l] > 0 && ps[2 * l + 1] > 0;
+        sum += ps[2 * l] * ps[2 * l + 1];
+    }
+    const int result = (sum == S ? 1 : 0) | (tiles && sum == S ? 2 : 0);
+    std::lock_guard<std::mutex> lock(g_pyr_mutex);
+    if (g_pyr_cache.size() >= 16) g_pyr_cache.erase(g_pyr_cache.begin());
+    g_pyr_cache.push_back({c10::weak_intrusive_ptr<c10::TensorImpl>(shapes.getIntrusivePtr()),
+                           c10::weak_intrusive_ptr<c10::TensorImpl>(starts.getIntrusivePtr()),
+                           is->version_counter().current_version(), it->version_counter().current_version(), S, result});
+    return result;
+}
+
+int self_attention_flags(const at::Tensor &shapes, const at::Tensor &starts, int Lq, int S)
+{
+    return (Lq == S && (pyramid_check(shapes, starts, S) & 2)) ? SEMIDETR_MSDA_QUERIES_ARE_PIXELS : 0;
+}
+
+void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+at::Tensor ms_deform_attn_forward(const at::Tensor &value, const at::Tensor &spatial_shapes,
+                                  const at::Tensor &level_start_index, const at::Tensor &sampling_loc,
+                                  const at::Tensor &attn_weight, int64_t im2col_step)
+{
+    const Dims d = op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
+                           "ms_deform_attn_forward_cuda");
+    const c10::hip::HIPGuard guard(value.device());
+    at::Tensor out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, value.options());      // the kernel writes all of it
+    if (out.numel() == 0 || value.numel() == 0) return out.zero_();
+    const int64_t *sh = spatial_shapes.data_ptr<int64_t>(), *ls = level_start_index.data_ptr<int64_t>();
+    int rc;
+    if (value.scalar_type() == at::kDouble)
+        rc = semidetr_msda_forward_f64(stream_of(value), value.data_ptr<double>(), sh, ls, sampling_loc.data_ptr<double>(),
+                                       attn_weight.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
+                                       out.data_ptr<double>());
+    else
+        rc = semidetr_msda_forward_f32(stream_of(value), value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
+                                       attn_weight.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
+                                       self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S),
+                                       out.data_ptr<float>());
+    check_rc(rc, "ms_deform_attn_forward");
+    return out;
+}
+
+std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor &value, const at::Tensor &spatial_shapes,
+                                                const at::Tensor &level_start_index, const at::Tensor &sampling_loc,
+                                                const at::Tensor &attn_weight, const at::Tensor &grad_output,
+                                                int64_t im2col_step)
+{
+    const Dims d = op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
+                           "ms_deform_attn_backward_cuda");
+    check_tensor(grad_output, value, "grad_output");
+    TORCH_CHECK(grad_output.scalar_type() == value.scalar_type() &&
+                    grad_output.numel() == (int64_t)d.N * d.Lq * d.M * d.D,
+                "ms_deform_attn_backward_cuda: grad_output must be (N, Lq, M*D) of value's dtype");
+    const c10::hip::HIPGuard guard(value.device());
+    at::Tensor gv = at::empty_like(value);            // zero-filled inside the call where the kernels need it
+    at::Tensor gl = at::empty_like(sampling_loc);     // fully written by the kernels
+    at::Tensor ga = at::empty_like(attn_weight);
+    if (value.numel() == 0 || gl.numel() == 0) return {gv.zero_(), gl.zero_(), ga.zero_()};
+    const int64_t *sh = spatial_shapes.data_ptr<int64_t>(), *ls = level_start_index.data_ptr<int64_t>();
+    int rc;
+    if (value.scalar_type() == at::kDouble)
+        rc = semidetr_msda_backward_f64(stream_of(value), grad_output.data_ptr<double>(), value.data_ptr<double>(), sh, ls,
+                                        sampling_loc.data_ptr<double>(), attn_weight.data_ptr<double>(), d.N, d.S, d.M,
+                                        d.D, d.L, d.Lq, d.P, gv.data_ptr<double>(), gl.data_ptr<double>(),
+                                        ga.data_ptr<double>());
+    else
+        rc = semidetr_msda_backward_f32(stream_of(value), grad_output.data_ptr<float>(), value.data_ptr<float>(), sh, ls,
+                                        sampling_loc.data_ptr<float>(), attn_weight.data_ptr<float>(), d.N, d.S, d.M, d.D,
+                                        d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S),
+                                        gv.data_ptr<float>(), gl.data_ptr<float>(), ga.data_ptr<float>());
+    check_rc(rc, "ms_deform_attn_backward");
+    return {gv, gl, ga};
+}
+
+// ---- fused prologue / epilogue (not part of the reference's pybind surface) ----------------------------------
+bool fused_supported(const at::Tensor &value, const at::Tensor &ref, const at::Tensor &off, const at::Tensor &logits)
+{
+    return value.is_cuda() && value.scalar_type() == at::kFloat && value.dim() == 4 && value.size(3) == 32 &&
+           value.size(2) <= 32 && (ref.size(-1) == 2 || ref.size(-1) == 4) && off.scalar_type() == at::kFloat &&
+           logits.scalar_type() == at::kFloat && ref.scalar_type() == at::kFloat;
+}
+
+Dims fused_dims(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor &starts, const at::Tensor &ref,
+                const at::Tensor &off, const at::Tensor &logits)
+{
+    TORCH_CHECK(value.is_cuda(), "Not implemented on the CPU");
+    check_tensor(value, value, "value");
+    check_tensor(shapes, value, "spatial_shapes");
+    check_tensor(starts, value, "level_start_index");
+    check_tensor(ref, value, "reference_points");
+    check_tensor(off, value, "sampling_offsets");
+    check_tensor(logits, value, "attention logits");
+    TORCH_CHECK(shapes.scalar_type() == at::kLong && starts.scalar_type() == at::kLong,
+                "expected scalar type Long for spatial_shapes / level_start_index");
+    TORCH_CHECK(value.dim() == 4 && off.dim() == 6 && logits.dim() == 4 && ref.dim() == 4,
+                "ms_deform_attn_fused: expected sampling_offsets (N,Lq,M,L,P,2), logits (N,Lq,M,L*P), reference "
+                "(N,Lq,L,2|4)");
+    TORCH_CHECK(value.scalar_type() == at::kFloat && off.scalar_type() == at::kFloat &&
+                    logits.scalar_type() == at::kFloat && ref.scalar_type() == at::kFloat,
+                "ms_deform_attn_fused: fp32 tensors only");
+    Dims d;
+    d.N = (int)value.size(0); d.S = (int)value.size(1); d.M = (int)value.size(2); d.D = (int)value.size(3);
+    d.Lq = (int)off.size(1); d.L = (int)off.size(3); d.P = (int)off.size(4);
+    TORCH_CHECK(off.size(0) == d.N && off.size(2) == d.M && off.size(5) == 2 && logits.size(0) == d.N &&
+                    logits.size(1) == d.Lq && logits.size(2) == d.M && logits.size(3) == (int64_t)d.L * d.P &&
+                    ref.size(0) == d.N && ref.size(1) == d.Lq && ref.size(2) == d.L && shapes.size(0) == d.L,
+                "ms_deform_attn_fused: inconsistent tensor shapes");
+    if (ref.size(-1) != 2 && ref.size(-1) != 4)
+        throw py::value_error("Last dim of reference_points must be 2 or 4, but get " + std::to_string(ref.size(-1)) +
+                              " instead.");
+    return d;
+}
+
+at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tensor &spatial_shapes,
+                                        const at::Tensor &level_start_index, const at::Tensor &reference_points,
+                                        const at::Tensor &sampling_offsets, const at::Tensor &attn_logits)
+{
+    const Dims d = fused_dims(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits);
+    const c10::hip::HIPGuard guard(value.device());
+    at::Tensor out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, value.options());
+    if (out.numel() == 0 || value.numel() == 0) return out.zero_();
+    const int rc = semidetr_msda_fused_forward_f32(
+        stream_of(value), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(),
+        reference_points.data_ptr<float>(), (int)reference_points.size(-1), sampling_offsets.data_ptr<float>(),
+        attn_logits.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
+        self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), out.data_ptr<float>());
+    check_rc(rc, "ms_deform_attn_fused_forward");
+    return out;
+}
+
+std::vector<at::Tensor> ms_deform_attn_fused_backward(const at::Tensor &value, const at::Tensor &spatial_shapes,
+                                                      const at::Tensor &level_start_index,
+                                                      const at::Tensor &reference_points,
+                                                      const at::Tensor &sampling_offsets, const at::Tensor &attn_logits,
+                                                      const at::Tensor &grad_output)
+{
+    const Dims d = fused_dims(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits);
+    TORCH_CHECK(grad_output.is_contiguous() && grad_output.numel() == (int64_t)d.N * d.Lq * d.M * d.D &&
+                    grad_output.scalar_type() == at::kFloat && grad_output.device() == value.device(),
+                "ms_deform_attn_fused_backward: grad_output must be a contiguous (N, Lq, M*D) tensor of value's dtype");
+    const c10::hip::HIPGuard guard(value.device());
+    at::Tensor gv = at::empty_like(value), go = at::empty_like(sampling_offsets), gl = at::empty_like(attn_logits);
+    if (value.numel() == 0 || go.numel() == 0) return {gv.zero_(), go.zero_(), gl.zero_()};
+    const int rc = semidetr_msda_fused_backward_f32(
+        stream_of(value), grad_output.data_ptr<float>(), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(),
+        level_start_index.data_ptr<int64_t>(), reference_points.data_ptr<float>(), (int)reference_points.size(-1),
+        sampling_offsets.data_ptr<float>(), attn_logits.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
+        self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), gv.data_ptr<float>(), go.data_ptr<float>(),
+        gl.data_ptr<float>());
+    check_rc(rc, "ms_deform_attn_fused_backward");
+    return {gv, go, gl};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "MultiScaleDeformableAttention for MI355X (gfx950): at::Tensor front end of libsemidetr_hip.so";
+    // the reference's surface (src/vision.cpp:13-16)
+    m.def("ms_deform_attn_forward", &ms_deform_attn_forward, "ms_deform_attn_forward");
+    m.def("ms_deform_attn_backward", &ms_deform_attn_backward, "ms_deform_attn_backward");
+    // additions
+    m.def("ms_deform_attn_fused_forward", &ms_deform_attn_fused_forward);
+    m.def("ms_deform_attn_fused_backward", &ms_deform_attn_fused_backward);
+    m.def("fused_supported", &fused_supported);
+    m.def("pyramid_check", &pyramid_check,
+          "bit 0: sum(H*W) == S; bit 1: level_start_index tiles [0, S) exactly.  Cached per tensor pair / version.");
+    m.def("abi_version", []() { return semidetr_abi_version(); });
+}

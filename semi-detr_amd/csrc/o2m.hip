@@ -111,7 +111,10 @@ __global__ __launch_bounds__(256) void o2m_assign_kernel(
         for (int t = 0; t < NQL; ++t) {
             const int q = lane + 64 * t;
             met[t] = -1.f;                         // not a query / already taken
-            if (q < Q) met[t] = ipow_(probs[(size_t)q * C + label], alpha) * ipow_(iou_(pb[q], gt), beta);
+            // a label outside [0, C) (an index error in the reference, o2m_assigner.py:98) never reads out of bounds:
+            // such a ground truth simply gets no candidates
+            if (q < Q && (unsigned)label < (unsigned)C)
+                met[t] = ipow_(probs[(size_t)q * C + label], alpha) * ipow_(iou_(pb[q], gt), beta);
         }
         for (int r = 0; r < topk; ++r) {
             float bv = -1.f;

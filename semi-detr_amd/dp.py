@@ -52,6 +52,9 @@ class FlatGradArena:
 
     def __init__(self, params, device=None, bucket_bytes=64 << 20):
         self.params = [p for p in params if p.requires_grad]
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("FlatGradArena: only fp32 parameters (the reference trains in fp32)")
         device = device or (self.params[0].device if self.params else torch.device("cpu"))
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
@@ -131,18 +134,215 @@ class ScalarReducer:
 
 
 def concat_all_gather_ragged(t, group=None):
-    """detr_ssod/models/utils/dist_utils.py:4-30: gather variable-length 1-D tensors from all ranks (used for
-    the GMM cost threshold, dino_detr_ssod.py:303).  Two small collectives: sizes, then padded payloads."""
+    """detr_ssod/models/utils/dist_utils.py:4-30: gather tensors whose FIRST dimension differs between ranks (the GMM
+    cost lists, dino_detr_ssod.py:303) and concatenate them along dim 0; trailing dimensions are kept, as the
+    reference does by padding dim 0.  Two small collectives: sizes, then padded payloads."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t
+    if t.dim() == 0:
+        raise ValueError("concat_all_gather_ragged: need at least one dimension to concatenate along")
     world = dist.get_world_size(group)
-    size = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    size = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size, group=group)
     sizes = [int(s.item()) for s in sizes]
     mx = max(sizes)
-    pad = t.new_zeros(mx)
-    pad[:t.numel()] = t.reshape(-1)
-    out = [t.new_zeros(mx) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return torch.cat([o[:n] for o, n in zip(out, sizes)])
+    pad = t.new_zeros((mx,) + tuple(t.shape[1:]))
+    pad[:t.shape[0]] = t
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad.contiguous(), group=group)
+    return torch.cat([o[:n] for o, n in zip(out, sizes)], 0)
+
+
+def reduce_mean(tensor, group=None):
+    """mmdet/core/utils/dist_utils.py:67-73, same contract: mean over ranks of a (small) tensor, returned as a new
+    tensor; the input itself when torch.distributed is not initialised."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor.div_(dist.get_world_size(group)), op=dist.ReduceOp.SUM, group=group)
+    return tensor
+
+
+def reduce_mean_many(values, device=None, group=None):
+    """All the scalar normalisers of one ``loss()`` call in ONE collective.  The reference calls ``reduce_mean`` on
+    ~60 one-element tensors per step (num_total_pos / cls_avg_factor / reg_avg_factor / sum_alignment_metrics per
+    decoder layer and per loss branch, dino_detr_ssod_head.py:683-852); here the loss collects them first and asks
+    once.  ``values``: list of python numbers or 0-d / 1-element tensors -> list of 0-d fp32 tensors (means over
+    ranks, in order).  Device = the first tensor's, or ``device``."""
+    if not values:
+        return []
+    if device is None:
+        device = next((v.device for v in values if torch.is_tensor(v)), torch.device("cpu"))
+    red = ScalarReducer(device, group)
+    for v in values:
+        red.add(v)
+    return red.reduce_mean()
+
+
+class FlatDDP(torch.nn.Module):
+    """Drop-in for the wrap at detr_ssod/apis/train.py:88-93::
+
+        model = MMDistributedDataParallel(model.cuda(), device_ids=[torch.cuda.current_device()],
+                                          broadcast_buffers=False, find_unused_parameters=find_unused_parameters)
+
+    Same constructor keywords, same ``.module`` attribute, ``train_step`` / ``val_step`` pass-through (what mmcv's
+    runner calls), parameters AND buffers broadcast from rank 0 once at construction (torch DDP's
+    ``_sync_module_states``), no per-forward buffer broadcast (only ``broadcast_buffers=False`` is supported -- the
+    reference's setting).  What differs is how the gradient mean is produced, MI355X-first:
+
+      * every trainable parameter's ``.grad`` is a view into ONE flat fp32 arena; a bucket is a slice of it, so the
+        all-reduce runs in place on HBM the gradients already live in (no bucket copy-in / copy-out);
+      * parameters are laid out in REVERSE registration order (the order backward produces them), buckets are few
+        and large (64 MiB default; xGMI is point-to-point, per-collective latency is what costs weak scaling);
+      * a ``register_post_accumulate_grad_hook`` per parameter counts its bucket down; a bucket is launched
+        (asynchronously, in bucket order on every rank) the moment its last gradient has been accumulated, so the
+        collectives overlap with the rest of backward; a callback queued on the autograd engine waits for them at
+        the end of backward and turns sums into means (RCCL: ``ReduceOp.AVG``, no extra pass);
+      * ``optimizer.zero_grad(set_to_none=True)`` (the torch >= 2 default, also what mmcv's OptimizerHook does)
+        drops the views: the hook notices a foreign ``.grad``, copies it into the arena and re-installs the view,
+        so gradients can never silently bypass the reduction.  ``zero_grad(set_to_none=False)`` or
+        ``FlatDDP.zero_grad()`` keeps the views and avoids that copy.
+    """
+
+    def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=False,
+                 find_unused_parameters=False, bucket_bytes=64 << 20, process_group=None):
+        super().__init__()
+        if broadcast_buffers:
+            raise NotImplementedError("FlatDDP: only broadcast_buffers=False (the reference's setting, "
+                                      "detr_ssod/apis/train.py:91) is supported")
+        self.module = module
+        self.group = process_group
+        self.find_unused_parameters = bool(find_unused_parameters)
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.require_backward_grad_sync = True
+        self._sync_module_states()
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.arena = FlatGradArena(list(reversed(params)), bucket_bytes=bucket_bytes)
+        self.params = self.arena.params                              # arena order = reverse registration order
+        self._views = [p.grad for p in self.params]
+        # bucket index of every parameter; a parameter that straddles a bucket boundary counts for every bucket it
+        # touches (buckets are equal slices of the arena, not parameter-aligned)
+        self._param_buckets, self._bucket_need = [], [0] * len(self.arena.buckets)
+        per = self.arena.buckets[0][1] - self.arena.buckets[0][0] if self.arena.buckets else 1
+        for off, p in zip(self.arena.offsets, self.params):
+            bs = list(range(off // per, (off + max(p.numel(), 1) - 1) // per + 1))
+            self._param_buckets.append(bs)
+            for b in bs:
+                self._bucket_need[b] += 1
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._avg = (self.world > 1 and dist.get_backend(process_group) == "nccl")
+        self._reset()
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self.params]
+
+    # -- construction-time state sync (torch DDP._sync_module_states): parameters and buffers from rank 0
+    def _sync_module_states(self):
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t.data, src=dist.get_global_rank(self.group, 0) if self.group else 0, group=self.group)
+
+    def _reset(self):
+        self._left = list(self._bucket_need)
+        self._fired = [False] * len(self.params)
+        self._next = 0
+        self._pending = []
+        self._callback_queued = False
+
+    # -- the hook autograd calls after a parameter's gradient has been accumulated
+    def _on_grad_ready(self, p):
+        i = self._index[id(p)]
+        view = self._views[i]
+        if p.grad is not view and (p.grad is None or p.grad.data_ptr() != view.data_ptr()):
+            if p.grad is not None:                   # zero_grad(set_to_none=True) dropped the view: bring it home
+                view.copy_(p.grad)
+            p.grad = view
+        if not self.require_backward_grad_sync or self.world == 1:
+            return
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        if self._fired[i]:                           # second accumulation into the same parameter in one backward
+            return
+        self._fired[i] = True
+        for b in self._param_buckets[i]:
+            self._left[b] -= 1
+        self._launch_ready()
+
+    def _launch_ready(self, force=False):
+        nb = len(self.arena.buckets)
+        while self._next < nb and (force or self._left[self._next] == 0):
+            s, e = self.arena.buckets[self._next]
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            self._pending.append(dist.all_reduce(self.arena.flat[s:e], op=op, group=self.group, async_op=True))
+            self._next += 1
+
+    def _finalize(self):
+        """End of backward: reduce what is left (unused parameters), wait, sums -> means."""
+        try:
+            unused = [i for i, f in enumerate(self._fired) if not f]
+            if unused and not self.find_unused_parameters:
+                raise RuntimeError(
+                    "FlatDDP: %d parameters did not receive a gradient in this backward pass. Pass "
+                    "find_unused_parameters=True (as cfg.find_unused_parameters does at detr_ssod/apis/train.py:85) "
+                    "if that is expected." % len(unused))
+            for i in unused:                         # contributes zero to the mean, like torch DDP
+                if self._views[i] is not self.params[i].grad:
+                    self.params[i].grad = self._views[i]
+                self._views[i].zero_()
+            self._launch_ready(force=True)
+            for w in self._pending:
+                w.wait()
+            if not self._avg:
+                self.arena.flat.div_(self.world)
+        finally:
+            self._reset()
+
+    # -- manual driving (bench.py emulates a backward pass whose kernels are not autograd nodes)
+    def mark_ready(self, params):
+        """Tell the reducer that the gradients of ``params`` are final, exactly as autograd's hook would."""
+        for p in params:
+            i = self._index[id(p)]
+            if not self._fired[i]:
+                self._fired[i] = True
+                for b in self._param_buckets[i]:
+                    self._left[b] -= 1
+        if self.world > 1 and self.require_backward_grad_sync:
+            self._launch_ready()
+
+    def finish(self):
+        """Counterpart of ``mark_ready`` when no autograd engine callback runs."""
+        if self.world > 1 and self.require_backward_grad_sync:
+            self._finalize()
+        else:
+            self._reset()
+
+    def zero_grad(self, set_to_none=False):
+        """Zero the arena in one launch and keep the views installed."""
+        self.arena.zero_()
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+
+    def no_sync(self):
+        """Gradient accumulation without communication (torch DDP.no_sync)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old = self.require_backward_grad_sync
+            self.require_backward_grad_sync = False
+            try:
+                yield
+            finally:
+                self.require_backward_grad_sync = old
+        return ctx()
+
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
+
+    def train_step(self, *inputs, **kwargs):     # mmcv MMDistributedDataParallel.train_step
+        return self.module.train_step(*inputs, **kwargs)
+
+    def val_step(self, *inputs, **kwargs):
+        return self.module.val_step(*inputs, **kwargs)

@@ -74,10 +74,26 @@ class _EmaTable:
 
 
 _table_cache = {}
+_last = None            # (teacher Parameter objects, student Parameter objects, table, calls since full validation)
+_REVALIDATE_EVERY = 256
 
 
 def ema_update_(teacher_params, student_params, momentum):
-    """In place: teacher <- momentum * teacher + (1 - momentum) * student for two parameter lists."""
+    """In place: teacher <- momentum * teacher + (1 - momentum) * student for two parameter lists.
+
+    The device-side pointer table is reused while the parameter lists are the same OBJECTS as in the previous call
+    (an identity scan, ~15 us for the 466 tensors of DINO-R50; rebuilding the (data_ptr, numel) key cost more host
+    time than the 98 us kernel).  The table keeps the tensors alive, so a stale entry can never point
+    at freed memory; a parameter re-pointed to new storage (`p.data = ...`) is caught by the full pointer
+    validation that still runs every 256th call and whenever the identity scan fails."""
+    global _last
+    teacher_params, student_params = list(teacher_params), list(student_params)
+    if _last is not None and len(_last[0]) == len(teacher_params) and len(_last[1]) == len(student_params) \
+            and _last[3] < _REVALIDATE_EVERY and all(a is b for a, b in zip(_last[0], teacher_params)) \
+            and all(a is b for a, b in zip(_last[1], student_params)):
+        _last[3] += 1
+        _last[2].launch(momentum)
+        return
     pairs = [(s.data, t.data) for s, t in zip(student_params, teacher_params)]
     pairs = [(s, t) for s, t in pairs if s.numel() > 0]
     if not pairs:
@@ -88,6 +104,8 @@ def ema_update_(teacher_params, student_params, momentum):
         if len(_table_cache) > 8:
             _table_cache.clear()
         table = _table_cache[key] = _EmaTable(pairs)
+        table.keepalive = pairs
+    _last = [teacher_params, student_params, table, 0]
     table.launch(momentum)
 
 
@@ -117,7 +135,8 @@ class MeanTeacher(_HookBase):
 
     @staticmethod
     def _unwrap(model):
-        return model.module if is_module_wrapper(model) else model
+        from .dp import FlatDDP
+        return model.module if isinstance(model, FlatDDP) or is_module_wrapper(model) else model
 
     def before_run(self, runner):
         model = self._unwrap(runner.model)

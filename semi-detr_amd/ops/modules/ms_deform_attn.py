@@ -71,7 +71,11 @@ class MSDeformAttn(nn.Module):
         True = padding.  Returns (N, Lq, C)."""
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        # The reference asserts `(shapes[:, 0] * shapes[:, 1]).sum() == Len_in` on a device tensor (ms_deform_attn.py:90):
+        # one blocking device-to-host copy per layer call, ~60 per SSOD step.  Same check, but answered from a cache keyed
+        # on the (spatial_shapes, level_start_index) tensors -- all layers of a forward pass share them, so at most one
+        # synchronisation per step, none when the caller keeps the two tensors alive between steps.
+        assert MSDA.pyramid_check(input_spatial_shapes, input_level_start_index, Len_in) & 1
         M, L, P = self.n_heads, self.n_levels, self.n_points
 
         value = self.value_proj(input_flatten)

@@ -37,4 +37,11 @@ def register_all(force=True):
         done.append("MeanTeacher")
     except ImportError:
         skipped.append("MeanTeacher")
+    try:       # so that mmcv's is_module_wrapper() (runner, hooks, checkpoint code) unwraps the DDP replacement
+        from mmcv.parallel import MODULE_WRAPPERS
+        from .dp import FlatDDP
+        MODULE_WRAPPERS.register_module(name="FlatDDP", force=force, module=FlatDDP)
+        done.append("FlatDDP")
+    except ImportError:
+        skipped.append("FlatDDP")
     return done, skipped

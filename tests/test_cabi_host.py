@@ -26,13 +26,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/semidetr_hip.h but not exported"
     assert sorted(semi_detr_amd._lib.SIGNATURES) == names
-    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 2
+    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 3
 
 
 def test_host_side_argument_errors_need_no_gpu():
     import semi_detr_amd
     lib = semi_detr_amd._lib.lib()
-    rc = lib.semidetr_msda_forward_f32(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, None)
+    rc = lib.semidetr_msda_forward_f32(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, None)
     assert rc == -1 and b"null pointer" in lib.semidetr_last_error()
     rc = lib.semidetr_ema_flat_f32(None, None, None, -5, 0.5)
     assert rc == -1
@@ -59,6 +59,24 @@ def test_no_cpu_fallback_anywhere():
         s.filter_pseudo_labels([torch.zeros(3, 5)], [torch.zeros(3)])
     with pytest.raises(RuntimeError):
         s.ema_update_([torch.zeros(3)], [torch.zeros(3)], 0.5)
+
+
+def test_compiled_front_end_is_the_reference_module_surface():
+    """`import MultiScaleDeformableAttention` resolves to the compiled extension's functions (the reference's pybind
+    surface, src/vision.cpp:13-16); the cached pyramid check answers from the host copy of the level table."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd
+    assert type(MSDA.ms_deform_attn_forward).__name__ == "builtin_function_or_method" or "pybind" in repr(MSDA.ms_deform_attn_forward)
+    assert semi_detr_amd.MultiScaleDeformableAttention._msda_ext.abi_version() == 3
+    sh, ls = torch.tensor([[2, 3], [1, 2]]), torch.tensor([0, 6])
+    assert MSDA.pyramid_check(sh, ls, 8) == 3
+    assert MSDA.pyramid_check(sh, ls, 8) == 3                      # cache hit
+    assert MSDA.pyramid_check(sh, torch.tensor([0, 5]), 8) == 1     # sum matches, levels overlap
+    assert MSDA.pyramid_check(sh, ls, 9) == 0
+    sh[1, 1] = 3                                                    # in-place edit bumps the version -> re-evaluated
+    assert MSDA.pyramid_check(sh, ls, 8) == 0 and MSDA.pyramid_check(sh, ls, 9) == 3
+    with pytest.raises(RuntimeError, match="value tensor has to be contiguous|Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward(torch.zeros(1, 4, 2, 2), sh, ls, torch.zeros(1, 1, 2, 2, 1, 2), torch.zeros(1, 1, 2, 2, 1), 64)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -115,7 +133,7 @@ def test_assigner_surface_and_registry():
         s.HungarianAssigner(cls_cost=dict(type="NoSuchCost"))
     done, skipped = registry.register_all()
     assert set(done) | set(skipped) == {"HungarianAssigner", "O2MAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost",
-                                        "MeanTeacher", "TaskAlignedFocalLoss"}
+                                        "MeanTeacher", "TaskAlignedFocalLoss", "FlatDDP"}
     o = s.O2MAssigner()
     assert o.candidate_topk == 13 and s.O2MAssigner(candidate_topk=5).candidate_topk == 5
     with pytest.raises(AssertionError, match="gt_bboxes_ignore"):
