@@ -11,8 +11,9 @@
 // section 8(f) row 1) and `pyramid_check`, the cached test behind SEMIDETR_MSDA_QUERIES_ARE_PIXELS.
 #include <torch/extension.h>
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// ROCm builds of torch present their devices as DeviceType::CUDA; these are the guard / stream types for that view
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <mutex>
 #include <vector>
@@ -124,7 +125,7 @@ int self_attention_flags(const at::Tensor &shapes, const at::Tensor &starts, int
     return (Lq == S && (pyramid_check(shapes, starts, S) & 2)) ? SEMIDETR_MSDA_QUERIES_ARE_PIXELS : 0;
 }
 
-void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 at::Tensor ms_deform_attn_forward(const at::Tensor &value, const at::Tensor &spatial_shapes,
                                   const at::Tensor &level_start_index, const at::Tensor &sampling_loc,
@@ -132,7 +133,7 @@ at::Tensor ms_deform_attn_forward(const at::Tensor &value, const at::Tensor &spa
 {
     const Dims d = op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
                            "ms_deform_attn_forward_cuda");
-    const c10::hip::HIPGuard guard(value.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
     at::Tensor out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, value.options());      // the kernel writes all of it
     if (out.numel() == 0 || value.numel() == 0) return out.zero_();
     const int64_t *sh = spatial_shapes.data_ptr<int64_t>(), *ls = level_start_index.data_ptr<int64_t>();
@@ -161,7 +162,7 @@ std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor &value, const a
     TORCH_CHECK(grad_output.scalar_type() == value.scalar_type() &&
                     grad_output.numel() == (int64_t)d.N * d.Lq * d.M * d.D,
                 "ms_deform_attn_backward_cuda: grad_output must be (N, Lq, M*D) of value's dtype");
-    const c10::hip::HIPGuard guard(value.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
     at::Tensor gv = at::empty_like(value);            // zero-filled inside the call where the kernels need it
     at::Tensor gl = at::empty_like(sampling_loc);     // fully written by the kernels
     at::Tensor ga = at::empty_like(attn_weight);
@@ -226,7 +227,7 @@ at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tenso
                                         const at::Tensor &sampling_offsets, const at::Tensor &attn_logits)
 {
     const Dims d = fused_dims(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits);
-    const c10::hip::HIPGuard guard(value.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
     at::Tensor out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, value.options());
     if (out.numel() == 0 || value.numel() == 0) return out.zero_();
     const int rc = semidetr_msda_fused_forward_f32(
@@ -248,7 +249,7 @@ std::vector<at::Tensor> ms_deform_attn_fused_backward(const at::Tensor &value, c
     TORCH_CHECK(grad_output.is_contiguous() && grad_output.numel() == (int64_t)d.N * d.Lq * d.M * d.D &&
                     grad_output.scalar_type() == at::kFloat && grad_output.device() == value.device(),
                 "ms_deform_attn_fused_backward: grad_output must be a contiguous (N, Lq, M*D) tensor of value's dtype");
-    const c10::hip::HIPGuard guard(value.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
     at::Tensor gv = at::empty_like(value), go = at::empty_like(sampling_offsets), gl = at::empty_like(attn_logits);
     if (value.numel() == 0 || go.numel() == 0) return {gv.zero_(), go.zero_(), gl.zero_()};
     const int rc = semidetr_msda_fused_backward_f32(
