@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 }
 
 #include "msda_fast.h"   // IO policies + the D == 32 fp32 kernels
+#include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
 
 int g_fwd_variant = 0, g_bwd_variant = 0;
 
@@ -360,9 +361,10 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * kD, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    if ((pixels && P == kPT && S < (1 << 24) && g_bwd_variant == 0) || g_bwd_variant == 64 || g_bwd_variant == 65 || g_bwd_variant == 66 || g_bwd_variant == 67) {
-        SEMIDETR_REQUIRE(pixels && P == kPT && S < (1 << 24), SEMIDETR_E_BADARG,
-                         "msda_backward: the windowed kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS, spatial_size < 2^24 and num_point == 4");
+    const bool dest_ok = L <= kDestMaxLevels, win_ok = P == kPT;
+    if ((pixels && S < (1 << 24) && (dest_ok || win_ok) && g_bwd_variant == 0) || (g_bwd_variant >= 64 && g_bwd_variant <= 73)) {
+        SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
+                         "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         {   // gather half: the two small gradients, streams like the forward
             const int gt = (Lq + 31) / 32;
             const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
@@ -380,11 +382,30 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                                    grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
         }
-        // patches are enumerated on the device (the level table lives in device memory); a workgroup takes
-        // patches slot, slot + tiles_bound, ... so any bound >= 1 is correct; this one covers the usual
-        // pyramids (about S / patch size, ragged edges included) in a single round.
+        // grad_value: destination-owned tiles (msda_dest.h) unless a windowed variant is forced (64..67) or the pyramid
+        // has more levels than the kernel's LDS tables hold
+        if (L <= kDestMaxLevels && (g_bwd_variant == 0 || (g_bwd_variant >= 70 && g_bwd_variant <= 73))) {
+            // grid sizing hint: about 2.5 units per 256 rows of a usual 4-level pyramid (coarse tiles are split);
+            // workgroups take units slot, slot + bound, ... so any bound >= 1 is correct
+            const int bound = (S / 256 + 1) * 3 + 64;
+            const int64_t grid = (int64_t)N * bound * M;
+            SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+            if (g_bwd_variant == 72)
+                hipLaunchKernelGGL((msda_bwd_dest_d32<IO, 16, 16, 8, 1>), dim3((unsigned)grid), dim3(kDestThreads), 0, st,
+                                   grad_out, spatial_shapes, level_start, io, S, M, L, P, bound, grad_value);
+            else if (g_bwd_variant == 71)
+                hipLaunchKernelGGL((msda_bwd_dest_d32<IO, 16, 16, 6>), dim3((unsigned)grid), dim3(kDestThreads), 0, st,
+                                   grad_out, spatial_shapes, level_start, io, S, M, L, P, bound, grad_value);
+            else
+                hipLaunchKernelGGL((msda_bwd_dest_d32<IO, 16, 16, 8>), dim3((unsigned)grid), dim3(kDestThreads), 0, st,
+                                   grad_out, spatial_shapes, level_start, io, S, M, L, P, bound, grad_value);
+            return semidetr::launch_status("msda_bwd_dest_d32");
+        }
+        // windowed (source-owned) kernel: patches are enumerated on the device (the level table lives in device
+        // memory); a workgroup takes patches slot, slot + tiles_bound, ... so any bound >= 1 is correct.
         // measured at the 800x1333 encoder shape, bs 4: 8x16 patches 687 us / 784 MB of row atomics, 16x16 patches
         // 593 us / 604 MB (fewer halo rows per query); 64 forces the small patch
+        SEMIDETR_REQUIRE(P == kPT, SEMIDETR_E_BADARG, "msda_backward: the windowed kernel needs num_point == 4");
         const bool big = g_bwd_variant != 64;
         const int patch = big ? 256 : 128;
         const int tiles_bound = (S + patch - 1) / patch * 5 / 4 + 4 * L;
