@@ -85,6 +85,28 @@ def dino_param_sizes():
     return sizes
 
 
+class StudentParams(torch.nn.Module):
+    """The student's parameter list (DINO-R50 + projector, ~60 M fp32) as a module FlatDDP can wrap, grouped by the
+    order backward finishes them: heads, decoder, encoder, backbone."""
+
+    def __init__(self, dev):
+        super().__init__()
+        sizes = dino_param_sizes()
+        nb = 3 + 9 * 16 + 3 * 4                        # ResNet-50 entries of dino_param_sizes()
+        enc = 6 * 16
+        dec = 6 * 22
+        split = {"backbone": sizes[:nb], "encoder": sizes[nb:nb + enc], "decoder": sizes[nb + enc:nb + enc + dec],
+                 "heads": sizes[nb + enc + dec:]}
+        extra = GRAD_ELEMS - sum(sizes)                # projector etc.: counted with the heads
+        if extra > 0:
+            split["heads"] = split["heads"] + [extra]
+        self.groups = {}
+        for name in ("backbone", "encoder", "decoder", "heads"):          # registration order = forward order
+            ps = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(n, device=dev)) for n in split[name]])
+            setattr(self, "p_" + name, ps)
+            self.groups[name] = list(ps)
+
+
 class Workload:
     def __init__(self, dev, seed):
         import semi_detr_amd as sda
@@ -109,7 +131,7 @@ class Workload:
             return (a / a.sum((-1, -2), keepdim=True)).contiguous()
 
         self.t = {}
-        for n in (1, 4):
+        for n in (1, 2, 4):
             self.t[("value", n)] = rand(n, S, M, D) * 0.01
             self.t[("enc_loc", n)] = (ref.view(1, S, 1, 1, 1, 2) + randn(n, S, M, L, P, 2) * inv).contiguous()
             self.t[("enc_attn", n)] = attn(n, S)
@@ -141,7 +163,7 @@ class Workload:
             cp = randn(B, NUM_QUERY, 80) * 3
             return bp, cp, gts * layers, labs * layers, metas * layers
 
-        self.match_sets = [problems(4, 1), problems(1, 7), problems(4, 7)]
+        self.match_sets = [problems(4, 1), problems(1, 7), problems(4, 7), problems(2, 7)]
         # teacher outputs of the 4 unlabeled images (last decoder layer): mostly background, clustered boxes
         self.t_logits = (randn(4, NUM_QUERY, 80) * 2.0 - 5.0).contiguous()
         k = NUM_QUERY // 8
@@ -158,6 +180,7 @@ class Workload:
         self.student = [randn(n) for n in sizes]
         self.groups = {}
         self.events = []
+        self.kernels = {}          # event group -> device kernels the library reports for it
 
     # -- group timing with events on the launch stream (torch's current stream is the stream we pass down)
     def _timed(self, name, launches, nbytes, fn):
@@ -177,7 +200,10 @@ class Workload:
         def run():
             for _ in range(reps):
                 MSDA.ms_deform_attn_forward(v, self.shapes, self.starts, loc, a, 64)
-        self._timed(f"msda_fwd_{kind}_bs{n}_Lq{lq}", reps, msda_alg_bytes(n, lq, False), run)
+        name = f"msda_fwd_{kind}_bs{n}_Lq{lq}"
+        self._timed(name, reps, msda_alg_bytes(n, lq, False), run)
+        if name not in self.kernels:
+            self.kernels[name] = self.sda._lib.lib().semidetr_msda_last_kernels().decode().split("+")
 
     def _bwd(self, kind, n, lq, reps):
         import MultiScaleDeformableAttention as MSDA
@@ -189,7 +215,10 @@ class Workload:
         def run():
             for _ in range(reps):
                 MSDA.ms_deform_attn_backward(v, self.shapes, self.starts, loc, a, go, 64)
-        self._timed(f"msda_bwd_{kind}_bs{n}_Lq{lq}", reps, msda_alg_bytes(n, lq, True), run)
+        name = f"msda_bwd_{kind}_bs{n}_Lq{lq}"
+        self._timed(name, reps, msda_alg_bytes(n, lq, True), run)
+        if name not in self.kernels:
+            self.kernels[name] = self.sda._lib.lib().semidetr_msda_last_kernels().decode().split("+")
 
     def _pseudo(self):
         # queued behind the teacher's forward; the lists are only needed where the unsupervised loss matches them
@@ -204,11 +233,14 @@ class Workload:
         self._timed("hungarian_batch", 1, 0,
                     lambda: self.asg.assign_batch(bp, cp, gts, labs, metas, check=False))
 
-    def step(self, reducer=None, record=False):
+    def step(self, ddp=None, record=False):
+        """`ddp`: the dp.FlatDDP wrapper of the student's parameter list (None on one GPU).  The MSDA backward launches
+        of this step are not autograd nodes, so the step tells the reducer which parameter groups have their final
+        gradients -- through FlatDDP.mark_ready, the same bucket bookkeeping the autograd hooks drive in training
+        (tests/test_dp_gloo.py runs those hooks under real autograd): decoder + heads after the decoder backward,
+        encoder after the encoder backward, backbone at the end of backward (FlatDDP.finish)."""
         self.record = record
         sda = self.sda
-        if reducer is not None:
-            reducer.start()
         self._timed("ema", 1, 12 * self.n_params, lambda: sda.ema_update_(self.teacher, self.student, 0.999))
         q, qd = NUM_QUERY, NUM_QUERY + DN_PAD
         self._fwd("enc", 1, S, 6); self._fwd("dec", 1, qd, 6)            # supervised student forward
@@ -220,15 +252,23 @@ class Workload:
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, qd, 6)            # student forward_dummy
         self._fwd("enc", 4, S, 6); self._fwd("dec", 4, qd, 6)            # teacher forward_dummy
         self._match(1); self._match(2)                                   # sup + unsup loss()
-        self._bwd("dec", 4, qd, 6)
-        if reducer is not None:
-            reducer.launch_ready(0.25)
-        self._bwd("enc", 4, S, 6)
-        if reducer is not None:
-            reducer.launch_ready(0.6)
-        self._bwd("dec", 1, qd, 6); self._bwd("enc", 1, S, 6)
-        if reducer is not None:
-            reducer.finish()
+        self._bwd("dec", 4, qd, 6); self._bwd("dec", 1, qd, 6)
+        if ddp is not None:
+            ddp.mark_ready(ddp.module.groups["heads"] + ddp.module.groups["decoder"])
+        self._bwd("enc", 4, S, 6); self._bwd("enc", 1, S, 6)
+        if ddp is not None:
+            ddp.mark_ready(ddp.module.groups["encoder"])
+            ddp.mark_ready(ddp.module.groups["backbone"])                 # the backbone's backward is not part of the path
+            ddp.finish()
+
+    def sup_step(self):
+        """BASELINE.json config 2: fully supervised DINO-R50, 800x1333, bs 2 on one GPU -- hot path only: 6 enc + 6 dec
+        MSDA forward (decoder with de-noising padding), 7 layers x 2 images of Hungarian matching, 6 + 6 MSDA backward."""
+        self.record = False
+        qd = NUM_QUERY + DN_PAD
+        self._fwd("enc", 2, S, 6); self._fwd("dec", 2, qd, 6)
+        self._match(3)
+        self._bwd("dec", 2, qd, 6); self._bwd("enc", 2, S, 6)
 
     def group_stats(self):
         torch.cuda.synchronize()
@@ -268,19 +308,37 @@ def _graph_time(fn, per_graph=20, reps=9, replays=5):
 
 
 def hbm_stream_peak(dev):
-    """Measured streaming rate of this GPU (device-to-device copy of 1 GiB: read + write), GB/s."""
-    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    """Best streaming rate this GPU shows, GB/s (read + write bytes of a 1 GiB float4 copy): the library's own
+    nontemporal float4 copy kernel (semidetr_stream_copy_f32) and torch's tensor.copy_ -- the larger of the two is the
+    denominator of `frac_hbm_measured` (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy)."""
+    import ctypes
+    import semi_detr_amd as sda
+    lib = sda._lib.lib()
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
     b = torch.empty_like(a)
-    for _ in range(3):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(10):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    stream = sda._lib.current_stream_ptr
+
+    def own():
+        sda._lib.check(lib.semidetr_stream_copy_f32(stream(), ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()),
+                                                    a.numel()), "stream_copy")
+
+    res = {}
+    for name, fn in (("own_float4_copy", own), ("torch_copy", lambda: b.copy_(a))):
+        for _ in range(3):
+            fn()
+        best = 0.0
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, 2 * a.numel() * 4 * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        res[name] = best
+    assert torch.equal(a[:4096], b[:4096]) and torch.equal(a[-4096:], b[-4096:])
+    return max(res.values()), res
 
 
 def _msda_case(dev, levels, N, Lq, encoder):
@@ -341,8 +399,9 @@ def microbench(dev, iters=200, warm=20):
     b = msda_alg_bytes(N, Lq, False) + msda_alg_bytes(N, Lq, True)
     res["alg_bytes"] = b
     res["frac_hbm_peak"] = b / (res["fwd_bwd_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9)
-    peak = hbm_stream_peak(dev)
+    peak, peaks = hbm_stream_peak(dev)
     res["hbm_stream_measured_gbs"] = peak
+    res["hbm_stream_by_method_gbs"] = peaks
     res["frac_hbm_measured"] = b / (res["fwd_bwd_us"] * 1e-6) / (peak * 1e9)
     sec = {}
     five = LEVELS + [(7, 11)]
@@ -363,41 +422,94 @@ def microbench(dev, iters=200, warm=20):
     return res
 
 
+def _encoder_inputs(dev, n, img_shapes=None):
+    """Encoder-layer inputs the way the DINO transformer builds them (transformer.py:675-691, :1117-1147): flattened
+    pyramid, per-level padding masks from the images' true sizes inside the 800x1333 batch canvas, reference points =
+    pixel centres / valid extent, scaled by the valid ratios.  img_shapes None: every image fills the canvas (no mask)."""
+    shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    src = torch.randn(n, S, 256, device=dev, requires_grad=True)
+    pos = torch.randn(n, S, 256, device=dev)
+    if img_shapes is None:
+        ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h,
+                                                    (torch.arange(w, device=dev) + 0.5) / w, indexing="ij"), -1)
+                         .flip(-1).reshape(-1, 2) for h, w in LEVELS])
+        return shapes, starts, src, pos, ref.view(1, S, 1, 2).expand(n, S, L, 2).contiguous(), None
+    masks, ratios = [], []
+    for h, w in LEVELS:
+        mk = torch.ones(n, h, w, dtype=torch.bool, device=dev)
+        for i, (ih, iw) in enumerate(img_shapes):
+            mk[i, :math.ceil(ih * h / 800), :math.ceil(iw * w / 1333)] = False
+        masks.append(mk)
+        vh, vw = (~mk[:, :, 0]).sum(1).float() / h, (~mk[:, 0, :]).sum(1).float() / w
+        ratios.append(torch.stack([vw, vh], -1))
+    vr = torch.stack(ratios, 1)                                           # (n, L, 2)
+    refs = []
+    for lvl, (h, w) in enumerate(LEVELS):
+        ry, rx = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, device=dev), torch.linspace(0.5, w - 0.5, w, device=dev),
+                                indexing="ij")
+        ry = ry.reshape(-1)[None] / (vr[:, None, lvl, 1] * h)
+        rx = rx.reshape(-1)[None] / (vr[:, None, lvl, 0] * w)
+        refs.append(torch.stack((rx, ry), -1))
+    ref = torch.cat(refs, 1)[:, :, None] * vr[:, None]                    # (n, S, L, 2)
+    return shapes, starts, src, pos, ref.contiguous(), torch.cat([m.flatten(1) for m in masks], 1)
+
+
 def module_bench(dev, iters=10):
-    """Next-row evidence: one encoder MSDeformAttn layer (bs 4, 800x1333, d_model
-    256) forward + backward with the prologue/epilogue fused into the sampling kernels vs the reference's
-    op-by-op sequence (torch softmax / location arithmetic around MSDeformAttnFunction).  Includes the four
-    Linear layers (hipBLASLt through torch) in both cases."""
+    """The nn.Module boundary: one encoder MSDeformAttn layer (bs 4, 800x1333, d_model
+    256) forward + backward, incl. the four Linear layers (hipBLASLt through torch):
+      * prologue/epilogue fused into the sampling kernels vs the reference's op-by-op sequence;
+      * the same with mixed img_shape (padding masks + valid-ratio scaled reference points, SURVEY 8(d));
+      * six stacked encoder layers, forward only, timed on the host clock AND with events: the reference's per-layer
+        `assert (...).sum() == Len_in` is a blocking device-to-host copy; here it is answered from a cache, so the host
+        runs ahead of the device (host time << device time) instead of draining the queue twelve times."""
     from semi_detr_amd import MSDeformAttn
     torch.manual_seed(0)
     m = MSDeformAttn(256, L, M, P).to(dev)
     with torch.no_grad():
         m.sampling_offsets.weight.normal_(0, 0.01)
         m.attention_weights.weight.normal_(0, 0.05)
-    shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
-    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
     n = 4
-    src = torch.randn(n, S, 256, device=dev, requires_grad=True)
-    pos = torch.randn(n, S, 256, device=dev)
-    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h,
-                                                (torch.arange(w, device=dev) + 0.5) / w, indexing="ij"), -1)
-                     .flip(-1).reshape(-1, 2) for h, w in LEVELS])
-    ref = ref.view(1, S, 1, 2).expand(n, S, L, 2).contiguous()
     res = {}
-    for fused in (True, False):
-        m.fuse_prologue = fused
+    mixed = [(800, 1333), (800, 1201), (750, 1333), (704, 1066)]
+    for tag, shp in (("", None), ("masked_", mixed)):
+        shapes, starts, src, pos, ref, mask = _encoder_inputs(dev, n, shp)
+        for fused in (True, False):
+            m.fuse_prologue = fused
+            for _ in range(2):
+                m(src + pos, ref, src, shapes, starts, mask).sum().backward()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(iters):
+                m(src + pos, ref, src, shapes, starts, mask).sum().backward()
+            e1.record()
+            torch.cuda.synchronize()
+            res[tag + ("fused_ms" if fused else "op_by_op_ms")] = e0.elapsed_time(e1) / iters
+    res["speedup"] = res["op_by_op_ms"] / res["fused_ms"]
+    # six stacked layers, forward only: host clock vs device clock
+    m.fuse_prologue = True
+    shapes, starts, src, pos, ref, mask = _encoder_inputs(dev, n, mixed)
+    with torch.no_grad():
+        x = src.detach()
         for _ in range(2):
-            m(src + pos, ref, src, shapes, starts).sum().backward()
+            for _ in range(6):
+                y = m(x + pos, ref, x, shapes, starts, mask)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
         e0.record()
         for _ in range(iters):
-            m(src + pos, ref, src, shapes, starts).sum().backward()
+            for _ in range(6):
+                y = m(x + pos, ref, x, shapes, starts, mask)
         e1.record()
+        host_ms = (time.perf_counter() - t0) * 1e3 / iters
         torch.cuda.synchronize()
-        res["fused_ms" if fused else "op_by_op_ms"] = e0.elapsed_time(e1) / iters
-    res["speedup"] = res["op_by_op_ms"] / res["fused_ms"]
-    res["what"] = "MSDeformAttn encoder layer fwd+bwd, bs4, Lq=S=22223, d_model 256, incl. Linear layers"
+        del y
+    res["stack6_fwd_device_ms"] = e0.elapsed_time(e1) / iters
+    res["stack6_fwd_host_enqueue_ms"] = host_ms
+    res["what"] = ("MSDeformAttn encoder layer fwd+bwd, bs4, Lq=S=22223, d_model 256, incl. Linear layers; masked_* = mixed "
+                   "img_shape with padding masks; stack6 = six layers forward, host enqueue time vs device time")
     return res
 
 
@@ -447,25 +559,12 @@ def warmup_stage_bench(dev, iters=20):
     return res
 
 
-def kernel_symbols(group):
-    """Device kernels behind an event-timed group (names as rocprofv3 prints them, profiles/r01_bench_kernel_stats.txt)."""
-    if group.startswith("msda_fwd_enc"):
-        return ["msda_fwd_d32<1, 4, 408, LocAttnIO>"]
-    if group.startswith("msda_bwd_enc"):
-        return ["__amd_rocclr_fillBufferAligned", "msda_bwd_gather_d32<LocAttnIO, 16, 408>",
-                "msda_bwd_scatter_d32_win<LocAttnIO, 16, 16, 32, 32>"]
-    if group.startswith("msda_fwd_dec"):
-        return ["msda_fwd_d32<1|2|4, 4, 0, LocAttnIO>"]
-    if group.startswith("msda_bwd_dec"):
-        return ["__amd_rocclr_fillBufferAligned", "msda_bwd_d32<8|32, LocAttnIO>"]
-    return []
-
-
 def cpu_baseline():
-    """The oracle (a C port of the reference arithmetic; the reference itself has no native CPU path --
-    ms_deform_attn_cpu.cpp:26,39 only raises) timed on this box's host cores with OpenMP on a bounded sample:
-    one image of the encoder shape and one of the decoder shape, forward + backward (backward scatter by
-    `omp atomic`).  Extrapolated linearly in batch to the launches of one step -> images/s."""
+    """The oracle (a C port of the reference arithmetic -- the reference itself has no native CPU path,
+    ms_deform_attn_cpu.cpp:26,39 only raises, and its Python path cannot travel to this box) timed on the host cores
+    on a bounded sample: MSDA forward + backward on one encoder-shape and one decoder-shape image (backward as
+    independent (head, level) tasks without atomics, and once serially), the 39 Hungarian problems of a step (oracle
+    cost matrix + LSAP) and one EMA pass over the 47 M parameters.  Extrapolated linearly in images to one step."""
     import oracle
     cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
@@ -487,13 +586,38 @@ def cpu_baseline():
         for _ in range(reps):
             oracle.msda_backward(value, shapes, loc, a, go, parallel=True)
         t[kind + "_b"] = (time.perf_counter() - t0) / reps
+        if kind == "enc":
+            t0 = time.perf_counter()
+            oracle.msda_backward(value, shapes, loc, a, go)
+            t["enc_b_serial"] = time.perf_counter() - t0
+    # matcher: 39 problems (Q=900, G~U[1,15]) -- cost matrix + LSAP per problem, as the reference does on the host
+    probs = []
+    for _ in range(39):
+        G = int(rng.integers(1, 16))
+        bp = np.concatenate([rng.random((NUM_QUERY, 2)), rng.random((NUM_QUERY, 2)) * 0.5 + 0.01], -1).astype(np.float32)
+        cp = (rng.standard_normal((NUM_QUERY, 80)) * 3).astype(np.float32)
+        xy = rng.random((G, 2)) * [1000, 560]
+        gt = np.concatenate([xy, xy + rng.random((G, 2)) * [300, 220] + 16], -1).astype(np.float32)
+        probs.append((bp, cp, gt, rng.integers(0, 80, G).astype(np.int64)))
+    t0 = time.perf_counter()
+    for bp, cp, gt, gl in probs:
+        oracle.hungarian_assign(bp, cp, gt, gl, 1333.0, 800.0)
+    t["match"] = time.perf_counter() - t0
+    n_par = sum(dino_param_sizes())
+    te, st = rng.random(n_par, dtype=np.float32), rng.random(n_par, dtype=np.float32)
+    t0 = time.perf_counter()
+    oracle.ema_update(te, st, 0.999)
+    t["ema"] = time.perf_counter() - t0
     fwd_imgs, bwd_imgs = 6 * (1 + 4 * 4), 6 * (1 + 4)          # image-layers per step (enc and dec alike)
-    step_s = fwd_imgs * (t["enc_f"] + t["dec_f"]) + bwd_imgs * (t["enc_b"] + t["dec_b"])
+    step_s = fwd_imgs * (t["enc_f"] + t["dec_f"]) + bwd_imgs * (t["enc_b"] + t["dec_b"]) + t["match"] + t["ema"]
     return {"value": IMAGES_PER_GPU / step_s, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle (C + OpenMP, %d threads) msda fwd+bwd on 1 encoder-shape image (Lq=22223, 3 reps) and "
-                      "1 decoder-shape image (Lq=1100, 20 reps), extrapolated to the step's 102 fwd / 30 bwd "
-                      "image-layers; matcher/EMA excluded" % cores,
-            "enc_fwd_s": t["enc_f"], "enc_bwd_s": t["enc_b"], "dec_fwd_s": t["dec_f"], "dec_bwd_s": t["dec_b"]}
+            "sample": "oracle (C + OpenMP, %d threads): msda fwd+bwd on 1 encoder-shape image (Lq=22223, 3 reps) and 1 "
+                      "decoder-shape image (Lq=1100, 20 reps), extrapolated to the step's 102 fwd / 30 bwd image-layers; "
+                      "backward = 32 independent (head, level) tasks, no atomics (serial backward stated beside it); "
+                      "+ 39 Hungarian problems (cost + LSAP, 1 thread) + one EMA pass over %d parameters (1 thread)"
+                      % (cores, n_par),
+            "enc_fwd_s": t["enc_f"], "enc_bwd_s": t["enc_b"], "enc_bwd_serial_1thread_s": t["enc_b_serial"],
+            "dec_fwd_s": t["dec_f"], "dec_bwd_s": t["dec_b"], "matcher_39_problems_s": t["match"], "ema_s": t["ema"]}
 
 
 def main():
@@ -515,10 +639,10 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     wl = Workload(dev, seed=1234 + rank)
-    reducer = None
+    ddp = None
     if world > 1:
-        grads = torch.randn(GRAD_ELEMS, device=dev)
-        reducer = dp.GradAllReducer(grads, bucket_bytes=64 << 20)
+        # the drop-in for MMDistributedDataParallel (detr_ssod/apis/train.py:88-93) around the student's parameter list
+        ddp = dp.FlatDDP(StudentParams(dev), broadcast_buffers=False, find_unused_parameters=False, bucket_bytes=64 << 20)
 
     def barrier():
         if world > 1:
@@ -526,11 +650,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        wl.step(reducer)
+        wl.step(ddp)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step(reducer, record=True)
+        wl.step(ddp, record=True)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -544,15 +668,38 @@ def main():
         stats = wl.group_stats()
         msda = {k: v for k, v in stats.items() if k.startswith("msda_")}
         dom_name = max(msda, key=lambda k: msda[k]["ms"])
-        dom = msda[dom_name]
-        dur_s = dom["ms"] * 1e-3 / dom["launches"]
-        achieved = dom["bytes"] / dur_s / 1e9
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (bench.py cannot collect counters itself)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pmc.get(dom_name, {}).get("hbm_bytes_corrected")
-        except (OSError, ValueError):
-            pass
+
+        def traffic_of(group):
+            """HBM-side bytes per launch of an event group, from the committed PMC passes of tools/measure_traffic.sh
+            (bench.py cannot collect counters itself).  The script stores the kernel names it measured; a mismatch with
+            what the library launched in THIS run means the JSON is stale -> no number rather than a wrong one."""
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            except (OSError, ValueError):
+                return None, None
+            e = pmc.get(group)
+            if not e or sorted(e.get("kernels", [])) != sorted(wl.kernels.get(group, [])):
+                return None, None
+            return e.get("hbm_bytes_corrected"), "profiles/r02_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, tools/measure_traffic.sh)"
+
+        def roofline_of(group):
+            g = msda[group]
+            dur_s = g["ms"] * 1e-3 / g["launches"]
+            ach = g["bytes"] / dur_s / 1e9
+            traffic, src = traffic_of(group)
+            return {"bound": "hbm", "kernel": group, "kernel_symbols": wl.kernels.get(group, []), "achieved": ach,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": src, "alg_bytes_per_launch": g["bytes"], "avg_launch_us": dur_s * 1e6,
+                    "launches_timed": g["launches"]}
+
+        # second view of the forward: corner rows through the L1 (vector-memory data return), 64 B/clk/CU at the
+        # maximum engine clock (MI355X_MICROARCH.md: 2400 MHz, 256 CUs).  Every sample reads 4 corners x 128 B.
+        fwd_name = "msda_fwd_enc_bs4_Lq%d" % S
+        fg = msda[fwd_name]
+        corner_bytes = 4 * S * M * L * P * 4 * 128
+        fdur = fg["ms"] * 1e-3 / fg["launches"]
+        clock_mhz = torch.cuda.get_device_properties(dev).clock_rate / 1e3 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2400.0
+        l1_peak = 256 * 64 * 2400e6 / 1e9
         out = {
             "metric": "images/sec/node DINO-R50 SSOD step (hot path: MSDA fwd/bwd + Hungarian + EMA/pseudo-label)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -564,19 +711,35 @@ def main():
                                    "EMA over %d params, teacher NMS + pseudo-label filter + box warp; dense GEMMs/backbone not included"
                                    % wl.n_params,
                        "images_per_gpu": IMAGES_PER_GPU,
-                       "parallelism": "dp%d image-sharded, grad all-reduce %d fp32 over RCCL" % (world, GRAD_ELEMS)
+                       "parallelism": "dp%d image-sharded, FlatDDP bucketed grad all-reduce of %d fp32 over RCCL" % (world, GRAD_ELEMS)
                        if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "kernel_symbols": kernel_symbols(dom_name), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
-                         if traffic else None,
-                         "alg_bytes_per_launch": dom["bytes"], "avg_launch_us": dur_s * 1e6,
-                         "launches_timed": dom["launches"]},
+            "roofline": roofline_of(dom_name),
+            "roofline_l1": {"bound": "l1_return", "kernel": fwd_name, "kernel_symbols": wl.kernels.get(fwd_name, []),
+                            "achieved": corner_bytes / fdur / 1e9, "peak": l1_peak, "unit": "GB/s",
+                            "frac": corner_bytes / fdur / 1e9 / l1_peak,
+                            "note": "corner rows (4 x 128 B per sample) / launch time vs 256 CU x 64 B/clk x 2400 MHz; "
+                                    "the clock under this load is lower (1.7 GHz observed, DESIGN.md 6); evidence that the L1 "
+                                    "path is NOT what binds: profiles/r02_fwd_resident_level_pmc.txt",
+                            "corner_bytes_per_launch": corner_bytes, "device_clock_mhz_reported": clock_mhz},
+            "rooflines_all_msda_groups": {k: {"frac_hbm_peak": roofline_of(k)["frac"], "avg_launch_us": roofline_of(k)["avg_launch_us"],
+                                              "kernels": wl.kernels.get(k, [])} for k in sorted(msda)},
             "breakdown_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(stats.items())},
             "group_gbs": {k: v["bytes"] * v["launches"] / (v["ms"] * 1e-3) / 1e9 for k, v in sorted(stats.items())
                           if v["bytes"]},
         }
         if world == 1 and not args.no_micro:      # single-GPU extras; at N > 1 the other ranks would only wait
+            # BASELINE.json config 2: supervised DINO-R50 bs 2 (hot path only), its own timed loop
+            for _ in range(2):
+                wl.sup_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                wl.sup_step()
+            torch.cuda.synchronize()
+            sup_s = (time.perf_counter() - t1) / args.steps
+            out["supervised_dino_bs2"] = {"images_per_s": 2 / sup_s, "ms_per_step": sup_s * 1e3,
+                                          "workload": "configs/dino_detr: 12 MSDA fwd + 12 MSDA bwd launches at bs 2 "
+                                                      "(Lq=22223 / 1100) + 14 Hungarian problems; no EMA / pseudo labels"}
             out["microbench"] = microbench(dev)
             out["module_fused_prologue"] = module_bench(dev)
             out["warmup_stage"] = warmup_stage_bench(dev)

@@ -114,6 +114,14 @@ int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const 
                                      int num_query, int num_point, int flags, float *grad_value,
                                      float *grad_sampling_offsets, float *grad_attn_logits);
 
+/* Names of the device kernels the LAST semidetr_msda_* call of the calling thread launched ("+"-separated, as the
+ * profiler prints their base names), so that a benchmark reports what actually ran instead of a hand-kept table. */
+const char *semidetr_msda_last_kernels(void);
+
+/* Measurement aid: float4 streaming copy of `numel` fp32 values (multiple of 4, 16-byte aligned) -- the best
+ * streaming rate of the box is what bench.py quotes `frac_hbm_measured` against. */
+int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel);
+
 /* TEST / TUNING ONLY -- not part of the re-entrant contract above: forces a kernel variant of the f32 /
  * channels==32 fast path for every later call of the process (0 = automatic choice; codes in DESIGN.md 2.3b).
  * Process-wide and not thread-safe; nothing in semi-detr_amd/ calls it, tests and tools/ reset it to (0, 0). */

@@ -68,8 +68,8 @@ def msda_forward(value, shapes, loc, attn, level_start=None):
 
 def msda_backward(value, shapes, loc, attn, grad_out, level_start=None, parallel=False):
     """-> grad_value, grad_loc, grad_attn (same shapes/dtype as value, loc, attn).
-    parallel=True uses all host cores with an atomic scatter (summation order not deterministic): for the
-    cpu_baseline timing only; parity tests use the serial, deterministic default."""
+    parallel=True runs the (image, head, level) slices of grad_value as independent OpenMP tasks (no atomics; the
+    result is bit-identical to the serial default, tests/test_oracle_msda.py checks that)."""
     dt = np.float64 if value.dtype == np.float64 else np.float32
     value, loc, attn, grad_out = _c(value, dt), _c(loc, dt), _c(attn, dt), _c(grad_out, dt)
     shapes = _c(shapes, np.int64)

@@ -28,6 +28,8 @@
 // CPU oracle; everything downstream may contract.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 
 int g_fwd_variant = 0, g_bwd_variant = 0;
 
+thread_local const char *g_last_kernels = "";
+
 int check_common(const void *value, const void *shapes, const void *starts, const void *loc,
                  const void *attn, int N, int S, int M, int D, int L, int Lq, int P, size_t elem)
 {
@@ -267,6 +271,7 @@ int forward_impl(void *stream, const T *value, const int64_t *shapes, const int6
     const int blocks = (int)((rows + 3) / 4);
     hipLaunchKernelGGL(msda_fwd_generic<T>, dim3(blocks), dim3(256), 0, semidetr::as_stream(stream), value,
                        shapes, starts, loc, attn, N, S, M, D, L, Lq, P, out);
+    g_last_kernels = "msda_fwd_generic";
     return semidetr::launch_status("msda_fwd_generic");
 }
 
@@ -283,6 +288,7 @@ int backward_impl(void *stream, const T *gout, const T *value, const int64_t *sh
     const int blocks = (int)((rows + 3) / 4);
     hipLaunchKernelGGL(msda_bwd_generic<T>, dim3(blocks), dim3(256), 0, semidetr::as_stream(stream), gout,
                        value, shapes, starts, loc, attn, N, S, M, D, L, Lq, P, gvalue, gloc, gattn);
+    g_last_kernels = "fillBufferAligned+msda_bwd_generic";
     return semidetr::launch_status("msda_bwd_generic");
 }
 
@@ -329,6 +335,24 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
 #define LAUNCH_FWD(SP, UN, PT, TILES)                                                                       \
     hipLaunchKernelGGL((msda_fwd_d32<SP, UN, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        lds, st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
+    if (g_fwd_variant == 500) {
+        SEMIDETR_REQUIRE(pixels, SEMIDETR_E_BADARG, "msda_forward: the resident-level kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS");
+        // grid sizing hint as for the patch kernel, in groups of kResGroup patches
+        const int G = ((S + 31) / 32 * 5 / 4 + 4 * L + kResGroup - 1) / kResGroup;
+        const size_t rlds = (size_t)(kResRows + 1) * 128 + (size_t)2 * 32 * (L * P + 1) * 32;
+        SEMIDETR_REQUIRE(rlds <= 160 * 1024, SEMIDETR_E_BADARG, "msda_forward: too many samples per query for the resident-level kernel");
+        static bool lds_ok = false;      // dynamic LDS above 64 KB has to be allowed once per kernel
+        if (!lds_ok) {
+            const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_d32_res<IO>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_forward: hipFuncSetAttribute: %s", hipGetErrorString(ae));
+            lds_ok = true;
+        }
+        hipLaunchKernelGGL((msda_fwd_d32_res<IO>), dim3((unsigned)(N * M * G)), dim3(512), rlds, st, value, spatial_shapes,
+                           level_start, io, S, M, L, P, G, out);
+        g_last_kernels = "msda_fwd_d32_res";
+        return semidetr::launch_status("msda_fwd_d32_res");
+    }
     if ((pixels && g_fwd_variant == 0) || g_fwd_variant == 408 || g_fwd_variant == 804 || g_fwd_variant == 216) {
         SEMIDETR_REQUIRE(pixels, SEMIDETR_E_BADARG, "msda_forward: patch tiling needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS");
         // grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges included)
@@ -341,6 +365,7 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
         else if (g_fwd_variant == 216) LAUNCH_FWD(1, 4, 216, bound);
         else if (g_fwd_variant == 804) LAUNCH_FWD(1, 4, 804, bound);
         else LAUNCH_FWD(1, 4, 408, bound);
+        g_last_kernels = "msda_fwd_d32<1, 4, 408";
         return semidetr::launch_status("msda_fwd_d32<patch>");
     }
     const int unroll = g_fwd_variant >= 10 && g_fwd_variant < 100 ? g_fwd_variant / 10 : 4;
@@ -348,6 +373,7 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
     else if (split == 2) LAUNCH_FWD(2, 4, 0, tiles);
     else LAUNCH_FWD(4, 4, 0, tiles);
 #undef LAUNCH_FWD
+    g_last_kernels = split == 1 ? "msda_fwd_d32<1, 4, 0" : (split == 2 ? "msda_fwd_d32<2, 4, 0" : "msda_fwd_d32<4, 4, 0");
     return semidetr::launch_status("msda_fwd_d32");
 }
 
@@ -361,8 +387,8 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * kD, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    const bool dest_ok = L <= kDestMaxLevels, win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && (dest_ok || win_ok) && g_bwd_variant == 0) || (g_bwd_variant >= 64 && g_bwd_variant <= 73)) {
+    const bool win_ok = P == kPT;
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || (g_bwd_variant >= 64 && g_bwd_variant <= 73)) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         {   // gather half: the two small gradients, streams like the forward
@@ -384,7 +410,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         }
         // grad_value: destination-owned tiles (msda_dest.h) unless a windowed variant is forced (64..67) or the pyramid
         // has more levels than the kernel's LDS tables hold
-        if (L <= kDestMaxLevels && (g_bwd_variant == 0 || (g_bwd_variant >= 70 && g_bwd_variant <= 73))) {
+        if (L <= kDestMaxLevels && g_bwd_variant >= 70 && g_bwd_variant <= 73) {
             // grid sizing hint: about 2.5 units per 256 rows of a usual 4-level pyramid (coarse tiles are split);
             // workgroups take units slot, slot + bound, ... so any bound >= 1 is correct
             const int bound = (S / 256 + 1) * 3 + 64;
@@ -399,6 +425,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             else
                 hipLaunchKernelGGL((msda_bwd_dest_d32<IO, 16, 16, 8>), dim3((unsigned)grid), dim3(kDestThreads), 0, st,
                                    grad_out, spatial_shapes, level_start, io, S, M, L, P, bound, grad_value);
+            g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_dest_d32";
             return semidetr::launch_status("msda_bwd_dest_d32");
         }
         // windowed (source-owned) kernel: patches are enumerated on the device (the level table lives in device
@@ -417,6 +444,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         else
             hipLaunchKernelGGL((msda_bwd_scatter_d32_win<IO, 8, 16, 24, 32>), dim3((unsigned)grid), dim3(kWinThreads),
                                0, st, grad_out, spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
+        g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_win";
         return semidetr::launch_status("msda_bwd_scatter_d32_win");
     }
     // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles
@@ -432,10 +460,13 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     if (rpb == 32) LAUNCH_BWD(32);
     else LAUNCH_BWD(8);
 #undef LAUNCH_BWD
+    g_last_kernels = rpb == 32 ? "fillBufferAligned+msda_bwd_d32<32" : "fillBufferAligned+msda_bwd_d32<8";
     return semidetr::launch_status("msda_bwd_d32");
 }
 
 }  // namespace
+
+extern "C" const char *semidetr_msda_last_kernels(void) { return g_last_kernels; }
 
 extern "C" void semidetr_msda_set_variant(int fwd_variant, int bwd_variant)
 {

@@ -830,3 +830,138 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Encoder self-attention forward with the COARSE LEVELS LDS-RESIDENT (fp32, D == 32).
+//
+// The patch kernel above is bound by the vector-memory path, not by HBM (TA busy ~80 %, 5.8 GB of corner rows per
+// bs-4 launch through the L1 at ~64 B/clk/CU).  The only lever is to take corner reads off that
+// path.  A whole coarse level of ONE (image, head) is small -- 13 x 21 pixels x 128 B = 35 KB at 800 x 1333 -- so a
+// workgroup that stays with one (image, head) can keep it in LDS for its whole life and serve every sample of that
+// level (P of the L*P samples of every query: 25 % of all corner reads for the DINO pyramid) with ds_read_b128.
+// Differences from the LDS-window experiments that lost twice: nothing is re-staged per patch (no
+// halo traffic, no per-level barriers, no miss bookkeeping -- a resident level is resident completely), and the
+// fine levels keep their 16 independent buffer loads in flight exactly as before.
+//   * 512 threads = two 4 x 8 query patches at a time; a workgroup takes kResGroup consecutive patches of one
+//     (image, head) -- re-staging the resident rows costs 35 KB per 8 patches, +1.7 % of the 262 KB of corner rows a
+//     patch reads -- and workgroups are numbered / rotated over heads exactly like the plain patch kernel, so the
+//     dispatch order, L2 locality and XCD balance that kernel was tuned for are kept.  (A first version with
+//     persistent workgroups pinned to one (image, head) for the whole launch had every XCD working on all 32 (image,
+//     head) slices at once and was slower than the plain kernel: 290 vs 245 us at bs 4.)
+//   * resident levels = the longest suffix of the pyramid whose pixels fit kResRows rows (chosen on the device from
+//     the level table); requires SEMIDETR_MSDA_QUERIES_ARE_PIXELS (levels tile [0, S) contiguously).
+//   * corners outside a resident level read a zero row kept behind the resident rows (the op's zero padding).
+// ---------------------------------------------------------------------------------------------
+constexpr int kResRows = 320;            // 40 KB of value rows per workgroup
+constexpr int kResGroup = 8;             // patches per workgroup (even: two are processed at a time)
+
+template <typename IO>
+__global__ __launch_bounds__(512, 4) void msda_fwd_d32_res(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int P, int groups_per_image, float *__restrict__ out)
+{
+    constexpr int RPB = 32, PH = 4, PW = 8;
+    extern __shared__ float4 smem[];
+    const int LP = L * P, LPP = LP + 1, Lq = S;
+    float4 *res = smem;                                              // (kResRows + 1) rows x 8 float4
+    int4 *rec_off_all = reinterpret_cast<int4 *>(smem + (kResRows + 1) * 8);
+    float4 *rec_w_all = smem + (kResRows + 1) * 8 + 2 * RPB * LPP;
+
+    const int b = blockIdx.x, g = b / M;
+    const int m = (b % M + g / (kHeadRun / kResGroup)) % M;          // head rotation as in tile_of_block
+    const int n = g / groups_per_image, slot = g % groups_per_image;
+    const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255;
+    int4 *rec_off = rec_off_all + sub * RPB * LPP;
+    float4 *rec_w = rec_w_all + sub * RPB * LPP;
+    const int rs = M * kD;
+
+    // ---- resident suffix of the pyramid
+    int res_from = L, res_rows = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        const int hw_ = (int)shapes[2 * l] * (int)shapes[2 * l + 1];
+        if (res_rows + hw_ > kResRows) break;
+        res_rows += hw_;
+        res_from = l;
+    }
+    const int res_start = res_from < L ? (int)starts[res_from] : S;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(value + ((int64_t)n * S + res_start) * rs + m * kD);
+        for (int i = tid; i < res_rows * 8; i += 512) res[i] = src[(int64_t)(i >> 3) * (rs / 4) + (i & 7)];
+        if (tid < 8) res[res_rows * 8 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const unsigned zero_row = (unsigned)res_rows * 128u;
+    const int kres = res_from * P;                                   // samples k >= kres are served from LDS
+
+    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)n * S * M * kD, (unsigned)S * M * kD * 4u);
+    // groups_per_image is a grid sizing hint: a workgroup takes patch groups slot, slot + hint, ... (see msda_fwd_d32)
+    for (int tile = slot * kResGroup + sub;; tile += (tile % kResGroup >= kResGroup - 2) ? (groups_per_image - 1) * kResGroup + 2 : 2) {
+        // both halves of the workgroup must take the same number of barriers: a half without a patch idles through them
+        const Patch pt = find_patch<PH, PW>(tile, shapes, starts, L);
+        const Patch p0 = sub ? find_patch<PH, PW>(tile - 1, shapes, starts, L) : pt;
+        if (p0.Hq == 0) return;                                      // the pair's first patch does not exist: done
+        __syncthreads();                                             // previous pair done with the records (and res loaded)
+        // ---- phase 1: sample records
+        if (pt.Hq)
+            for (int s = t; s < RPB * LP; s += 256) {
+                const int r = s / LP, k = s - r * LP;
+                const int q = patch_query<PW>(pt, r);
+                unsigned off[4] = {kOob, kOob, kOob, kOob};
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int l = k / P;
+                const bool resident = l >= res_from;
+                if (resident) off[0] = off[1] = off[2] = off[3] = zero_row;
+                if (q >= 0) {
+                    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+                    const int64_t nq = (int64_t)n * Lq + q, row = nq * M + m;
+                    float x, y, lw, lh;
+                    io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
+                    const float a = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+                    unsigned o4[4];
+                    // resident levels: row pitch 128 B, pixel index relative to the first resident pixel
+                    if (sample_setup_oob(x, y, H, W, resident ? st - res_start : st, resident ? 128u : (unsigned)rs * 4u,
+                                         o4, lw, lh)) {
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        w = make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) off[i] = (resident && o4[i] == kOob) ? zero_row : o4[i];
+                    }
+                }
+                rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
+                rec_w[r * LPP + k] = w;
+            }
+        __syncthreads();
+        if (!pt.Hq) continue;
+        // ---- phase 2: gather + weighted sum; fine levels through the buffer path, resident levels from LDS
+        const int r = t >> 3, j = t & 7;
+        const int q = patch_query<PW>(pt, r);
+        const unsigned lane_b = (unsigned)(m * kD + 4 * j) * 4u;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int4 *ro = rec_off + r * LPP;
+        const float4 *rw = rec_w + r * LPP;
+        auto fma4 = [&](const float4 &w, const float4 &v1, const float4 &v2, const float4 &v3, const float4 &v4) {
+            acc.x += w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
+            acc.y += w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
+            acc.z += w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
+            acc.w += w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
+        };
+        const char *resb = reinterpret_cast<const char *>(res) + j * 16;
+#pragma unroll 4
+        for (int k = 0; k < kres; ++k) {
+            const int4 o = ro[k];
+            const float4 w = rw[k];
+            fma4(w, buf_ld4(vr, (unsigned)o.x + lane_b), buf_ld4(vr, (unsigned)o.y + lane_b),
+                 buf_ld4(vr, (unsigned)o.z + lane_b), buf_ld4(vr, (unsigned)o.w + lane_b));
+        }
+#pragma unroll 4
+        for (int k = kres; k < LP; ++k) {
+            const int4 o = ro[k];
+            const float4 w = rw[k];
+            fma4(w, *reinterpret_cast<const float4 *>(resb + o.x), *reinterpret_cast<const float4 *>(resb + o.y),
+                 *reinterpret_cast<const float4 *>(resb + o.z), *reinterpret_cast<const float4 *>(resb + o.w));
+        }
+        if (q >= 0) {
+            const int64_t row = ((int64_t)n * Lq + q) * M + m;
+            *reinterpret_cast<float4 *>(out + row * kD + 4 * j) = acc;
+        }
+    }
+}

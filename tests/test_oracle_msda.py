@@ -71,3 +71,18 @@ def test_module_d32_fixture_inputs_regenerate():
         got = [t.double().sum().item() for t in (query, src, ref, gout)] + [sd[k].double().sum().item() for k in sorted(sd)]
         np.testing.assert_allclose(got, g[name]["input_checksum"], rtol=1e-12)
         assert g[name]["out"].shape == (2, query.shape[1], 256)
+
+
+def test_parallel_oracle_backward_is_bit_identical_to_serial():
+    rng = np.random.default_rng(9)
+    shapes = np.asarray([(9, 13), (5, 7), (3, 4)], np.int64)
+    N, M, D, Lq, L, P = 2, 4, 32, 57, 3, 4
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = rng.random((N, S, M, D)).astype(np.float32)
+    loc = (rng.random((N, Lq, M, L, P, 2)) * 1.3 - 0.15).astype(np.float32)
+    attn = rng.random((N, Lq, M, L, P)).astype(np.float32)
+    gout = rng.random((N, Lq, M * D)).astype(np.float32)
+    a = oracle.msda_backward(value, shapes, loc, attn, gout)
+    b = oracle.msda_backward(value, shapes, loc, attn, gout, parallel=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--fvariant", type=int, default=None)
     ap.add_argument("--sigma", type=float, default=2.0, help="encoder sample spread in pixels")
+    ap.add_argument("--print-kernels", action="store_true", help="print what the library says it launched (KERNELS=...)")
     a = ap.parse_args()
     import semi_detr_amd as sda
     import MultiScaleDeformableAttention as MSDA
@@ -62,6 +63,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.iters
+        if a.print_kernels:
+            print("KERNELS=" + sda._lib.lib().semidetr_msda_last_kernels().decode())
         b = bench.msda_alg_bytes(n, lq, bw)
         print(f"{a.shape} bs{n} Lq{lq} {name} variant{a.variant}: {us:9.1f} us  alg {b/1e6:8.1f} MB  "
               f"{b/us/1e3:8.1f} GB/s  ({b/us/1e3/80:5.1f}% of 8 TB/s)")
