@@ -335,21 +335,31 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
 #define LAUNCH_FWD(SP, UN, PT, TILES)                                                                       \
     hipLaunchKernelGGL((msda_fwd_d32<SP, UN, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        lds, st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
-    if (g_fwd_variant == 500) {
+    if (g_fwd_variant >= 500 && g_fwd_variant <= 505) {
         SEMIDETR_REQUIRE(pixels, SEMIDETR_E_BADARG, "msda_forward: the resident-level kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS");
-        // grid sizing hint as for the patch kernel, in groups of kResGroup patches
-        const int G = ((S + 31) / 32 * 5 / 4 + 4 * L + kResGroup - 1) / kResGroup;
+        // 500: 8 patches per workgroup, coarse levels resident; 501: same schedule, nothing resident (control);
+        // 502 / 503: 4 patches per workgroup resident / control; 504 / 505: 2 patches
+        const int grp = g_fwd_variant <= 501 ? 8 : (g_fwd_variant <= 503 ? 4 : 2);
+        const int res_max = (g_fwd_variant & 1) ? 0 : kResRows;
+        const int G = ((S + 31) / 32 * 5 / 4 + 4 * L + grp - 1) / grp;      // grid sizing hint as for the patch kernel
         const size_t rlds = (size_t)(kResRows + 1) * 128 + (size_t)2 * 32 * (L * P + 1) * 32;
         SEMIDETR_REQUIRE(rlds <= 160 * 1024, SEMIDETR_E_BADARG, "msda_forward: too many samples per query for the resident-level kernel");
-        static bool lds_ok = false;      // dynamic LDS above 64 KB has to be allowed once per kernel
-        if (!lds_ok) {
-            const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_d32_res<IO>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_forward: hipFuncSetAttribute: %s", hipGetErrorString(ae));
-            lds_ok = true;
-        }
-        hipLaunchKernelGGL((msda_fwd_d32_res<IO>), dim3((unsigned)(N * M * G)), dim3(512), rlds, st, value, spatial_shapes,
-                           level_start, io, S, M, L, P, G, out);
+#define LAUNCH_RES(GRP)                                                                                              \
+        do {                                                                                                             \
+            static bool lds_ok = false; /* dynamic LDS above 64 KB has to be allowed once per kernel */                \
+            if (!lds_ok) {                                                                                               \
+                const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_d32_res<IO, GRP>),   \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+                if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_forward: hipFuncSetAttribute: %s", hipGetErrorString(ae)); \
+                lds_ok = true;                                                                                           \
+            }                                                                                                            \
+            hipLaunchKernelGGL((msda_fwd_d32_res<IO, GRP>), dim3((unsigned)(N * M * G)), dim3(512), rlds, st, value,     \
+                               spatial_shapes, level_start, io, S, M, L, P, G, res_max, out);                          \
+        } while (0)
+        if (grp == 8) LAUNCH_RES(8);
+        else if (grp == 4) LAUNCH_RES(4);
+        else LAUNCH_RES(2);
+#undef LAUNCH_RES
         g_last_kernels = "msda_fwd_d32_res";
         return semidetr::launch_status("msda_fwd_d32_res");
     }

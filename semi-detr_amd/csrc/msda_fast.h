@@ -853,12 +853,10 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
 //   * corners outside a resident level read a zero row kept behind the resident rows (the op's zero padding).
 // ---------------------------------------------------------------------------------------------
 constexpr int kResRows = 320;            // 40 KB of value rows per workgroup
-constexpr int kResGroup = 8;             // patches per workgroup (even: two are processed at a time)
-
-template <typename IO>
+template <typename IO, int kResGroup = 8>   // patches per workgroup (even: two are processed at a time)
 __global__ __launch_bounds__(512, 4) void msda_fwd_d32_res(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
-    const IO io, int S, int M, int L, int P, int groups_per_image, float *__restrict__ out)
+    const IO io, int S, int M, int L, int P, int groups_per_image, int res_rows_max, float *__restrict__ out)
 {
     constexpr int RPB = 32, PH = 4, PW = 8;
     extern __shared__ float4 smem[];
@@ -868,7 +866,7 @@ __global__ __launch_bounds__(512, 4) void msda_fwd_d32_res(
     float4 *rec_w_all = smem + (kResRows + 1) * 8 + 2 * RPB * LPP;
 
     const int b = blockIdx.x, g = b / M;
-    const int m = (b % M + g / (kHeadRun / kResGroup)) % M;          // head rotation as in tile_of_block
+    const int m = (b % M + g / (kHeadRun / kResGroup > 0 ? kHeadRun / kResGroup : 1)) % M;   // head rotation as in tile_of_block
     const int n = g / groups_per_image, slot = g % groups_per_image;
     const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255;
     int4 *rec_off = rec_off_all + sub * RPB * LPP;
@@ -879,7 +877,7 @@ __global__ __launch_bounds__(512, 4) void msda_fwd_d32_res(
     int res_from = L, res_rows = 0;
     for (int l = L - 1; l >= 0; --l) {
         const int hw_ = (int)shapes[2 * l] * (int)shapes[2 * l + 1];
-        if (res_rows + hw_ > kResRows) break;
+        if (res_rows + hw_ > res_rows_max) break;
         res_rows += hw_;
         res_from = l;
     }

@@ -10,6 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // every thread moves kPer consecutive-by-stride float4s; loads first, then stores (kPer independent requests in flight)
 constexpr int kPer = 8;
+template <bool NT>
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
                                                           int64_t n4)
 {
@@ -18,16 +19,19 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4 *__restric
         f32x4 v[kPer];
 #pragma unroll
         for (int i = 0; i < kPer; ++i)
-            if (base + i * stride < n4) v[i] = __builtin_nontemporal_load(src + base + i * stride);
+            if (base + i * stride < n4) v[i] = NT ? __builtin_nontemporal_load(src + base + i * stride) : src[base + i * stride];
 #pragma unroll
         for (int i = 0; i < kPer; ++i)
-            if (base + i * stride < n4) __builtin_nontemporal_store(v[i], dst + base + i * stride);
+            if (base + i * stride < n4) {
+                if (NT) __builtin_nontemporal_store(v[i], dst + base + i * stride);
+                else dst[base + i * stride] = v[i];
+            }
     }
 }
 
 }  // namespace
 
-extern "C" int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel)
+extern "C" int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel, int nontemporal)
 {
     SEMIDETR_REQUIRE(dst && src && numel > 0 && numel % 4 == 0, SEMIDETR_E_BADARG,
                      "stream_copy: need non-null pointers and a positive multiple of 4 elements");
@@ -35,7 +39,11 @@ extern "C" int semidetr_stream_copy_f32(void *stream, float *dst, const float *s
     const int64_t n4 = numel / 4;
     const int64_t want = (n4 + 256 * kPer - 1) / (256 * kPer);
     const unsigned grid = (unsigned)(want < 256 * 32 ? (want > 0 ? want : 1) : 256 * 32);
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, semidetr::as_stream(stream),
-                       reinterpret_cast<const f32x4 *>(src), reinterpret_cast<f32x4 *>(dst), n4);
+    if (nontemporal)
+        hipLaunchKernelGGL(stream_copy_kernel<true>, dim3(grid), dim3(256), 0, semidetr::as_stream(stream),
+                           reinterpret_cast<const f32x4 *>(src), reinterpret_cast<f32x4 *>(dst), n4);
+    else
+        hipLaunchKernelGGL(stream_copy_kernel<false>, dim3(grid), dim3(256), 0, semidetr::as_stream(stream),
+                           reinterpret_cast<const f32x4 *>(src), reinterpret_cast<f32x4 *>(dst), n4);
     return semidetr::launch_status("stream_copy_kernel");
 }
