@@ -387,6 +387,99 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
     return semidetr::launch_status("msda_fwd_d32");
 }
 
+// ---- strips backward (any query set).  Experiment (variants 808 / 832): SPLIT in two launches so that the zero fill of
+// grad_value overlaps the half that does not need it: a side stream (one per host thread, joined back before the call returns to the caller's
+// stream order) runs the fill while the caller's stream runs msda_bwd_gather_d32 (grad_sampling_loc / grad_attn_weight:
+// reads value corners, never touches grad_value); the scatter-only instantiation of msda_bwd_d32 follows once both are
+// done.  At the BASELINE micro-benchmark shape the 45.5 MB fill is 7-8 us of a 43 us backward.  Works under stream
+// capture (the side stream forks from and joins the capturing stream through events).
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+};
+thread_local SideStream g_side;
+
+int side_stream(SideStream **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward: hipGetDevice: %s", hipGetErrorString(e));
+    if (g_side.device != dev) {      // first call of this thread on this device (objects of another device are leaked: rare)
+        e = hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming);
+        if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward: side stream: %s", hipGetErrorString(e));
+        g_side.device = dev;
+    }
+    *out = &g_side;
+    return SEMIDETR_OK;
+}
+
+// zero-fill `bytes` at `ptr` on the side stream, ordered after everything already queued on `st`
+int fill_on_side(hipStream_t st, void *ptr, size_t bytes, SideStream **side)
+{
+    if (int rc = side_stream(side)) return rc;
+    hipError_t e = hipEventRecord((*side)->fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent((*side)->s, (*side)->fork, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(ptr, 0, bytes, (*side)->s);
+    if (e == hipSuccess) e = hipEventRecord((*side)->join, (*side)->s);
+    if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward fill on the side stream: %s", hipGetErrorString(e));
+    return SEMIDETR_OK;
+}
+int join_side(hipStream_t st, SideStream *side)
+{
+    const hipError_t e = hipStreamWaitEvent(st, side->join, 0);
+    if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward join: %s", hipGetErrorString(e));
+    return SEMIDETR_OK;
+}
+
+template <typename IO>
+int launch_strips_backward(hipStream_t st, size_t fill, const float *grad_out, const float *value,
+                           const int64_t *spatial_shapes, const int64_t *level_start, const IO &io, int N, int S, int M,
+                           int L, int Lq, int P, int rpb, int tiles, unsigned grid, size_t lds, float *grad_value)
+{
+    // default: ONE kernel after the fill on the caller's stream.  The split below lost on MI355X (measured, r02): the
+    // fork / join through events costs more than the 7-8 us of fill it hides -- micro-benchmark backward 42.8 -> 63.1 us,
+    // decoder bs 4 242 -> 267 us, encoder bs 4 875 -> 893 us.  Kept selectable (808 / 832) as the evidence.
+    const bool fused = g_bwd_variant != 808 && g_bwd_variant != 832;
+    if (fused) {
+        hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
+        if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+        if (rpb == 32)
+            hipLaunchKernelGGL((msda_bwd_d32<32, IO>), dim3(grid), dim3(256), lds, st, grad_out, value, spatial_shapes,
+                               level_start, io, S, M, L, Lq, P, tiles, grad_value);
+        else
+            hipLaunchKernelGGL((msda_bwd_d32<8, IO>), dim3(grid), dim3(256), lds, st, grad_out, value, spatial_shapes,
+                               level_start, io, S, M, L, Lq, P, tiles, grad_value);
+        g_last_kernels = rpb == 32 ? "fillBufferAligned+msda_bwd_d32<32" : "fillBufferAligned+msda_bwd_d32<8";
+        return semidetr::launch_status("msda_bwd_d32");
+    }
+    SideStream *side = nullptr;
+    if (int rc = fill_on_side(st, grad_value, fill, &side)) return rc;
+    {   // the two small gradients (32 query rows per workgroup)
+        const int gt = (Lq + 31) / 32;
+        const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
+        if (L * P == 16)
+            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
+                               grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
+        else
+            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
+                               grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
+        const int grc = semidetr::launch_status("msda_bwd_gather_d32");
+        if (int rc = join_side(st, side)) return rc;            // never leave the side stream un-joined
+        if (grc) return grc;
+    }
+    if (rpb == 32)
+        hipLaunchKernelGGL((msda_bwd_d32<32, IO, true>), dim3(grid), dim3(256), lds, st, grad_out, value, spatial_shapes,
+                           level_start, io, S, M, L, Lq, P, tiles, grad_value);
+    else
+        hipLaunchKernelGGL((msda_bwd_d32<8, IO, true>), dim3(grid), dim3(256), lds, st, grad_out, value, spatial_shapes,
+                           level_start, io, S, M, L, Lq, P, tiles, grad_value);
+    g_last_kernels = rpb == 32 ? "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_d32<32" : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_d32<8";
+    return semidetr::launch_status("msda_bwd_d32<scatter>");
+}
+
 template <typename IO>
 int launch_fast_backward(hipStream_t st, const float *grad_out, const float *value, const int64_t *spatial_shapes,
                          const int64_t *level_start, const IO &io, int N, int S, int M, int L, int Lq, int P,
@@ -395,12 +488,13 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0;
     SEMIDETR_REQUIRE(!pixels || Lq == S, SEMIDETR_E_BADARG,
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
-    hipError_t e = hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)N * S * M * kD, st);
-    if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+    const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
     if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || (g_bwd_variant >= 64 && g_bwd_variant <= 73)) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
+        hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
+        if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
         {   // gather half: the two small gradients, streams like the forward
             const int gt = (Lq + 31) / 32;
             const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
@@ -459,19 +553,14 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     }
     // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles
     int rpb = (int64_t)N * M * ((Lq + 31) / 32) >= 1024 ? 32 : 8;
-    if (g_bwd_variant == 8 || g_bwd_variant == 32) rpb = g_bwd_variant;
+    if (g_bwd_variant == 8 || g_bwd_variant == 32) rpb = g_bwd_variant % 100;
+    if (g_bwd_variant == 808 || g_bwd_variant == 832) rpb = g_bwd_variant - 800;
     const int tiles = (Lq + rpb - 1) / rpb;
     const int64_t grid = (int64_t)N * tiles * M;
     SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
     const size_t lds = (size_t)rpb * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
-#define LAUNCH_BWD(R)                                                                                       \
-    hipLaunchKernelGGL((msda_bwd_d32<R, IO>), dim3((unsigned)grid), dim3(256), lds, st, grad_out, value,    \
-                       spatial_shapes, level_start, io, S, M, L, Lq, P, tiles, grad_value)
-    if (rpb == 32) LAUNCH_BWD(32);
-    else LAUNCH_BWD(8);
-#undef LAUNCH_BWD
-    g_last_kernels = rpb == 32 ? "fillBufferAligned+msda_bwd_d32<32" : "fillBufferAligned+msda_bwd_d32<8";
-    return semidetr::launch_status("msda_bwd_d32");
+    return launch_strips_backward<IO>(st, fill, grad_out, value, spatial_shapes, level_start, io, N, S, M, L, Lq, P, rpb,
+                                      tiles, (unsigned)grid, lds, grad_value);
 }
 
 }  // namespace

@@ -302,7 +302,9 @@ __device__ __forceinline__ float half32_sum(float x)
 // atomics cost ~one unit per 64-byte half-line touched (~20.8 G units/s chip-wide), so full-row updates move
 // 4x more gradient per unit than the 8-lane x float4 layout the forward uses.
 // RPB = query rows per 256-thread workgroup (8 half-waves, each walks RPB/8 rows).
-template <int RPB, typename IO = LocAttnIO>
+// SCATTER_ONLY: grad_value only (no value reads, no channel reductions, no small gradients) -- the second half of the
+// split backward, whose first half (msda_bwd_gather_d32) runs while grad_value is still being zero-filled.
+template <int RPB, typename IO = LocAttnIO, bool SCATTER_ONLY = false>
 __global__ __launch_bounds__(256) void msda_bwd_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image,
@@ -362,6 +364,13 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
             const int l = __float_as_int(pr.w);
             const float hh = 1.f - lh, hwt = 1.f - lw;
             const float ga = go * a;
+            if (SCATTER_ONLY) {
+                if ((unsigned)o.x != kOob) fp_atomic_add(gvb + ((unsigned)o.x >> 2), hh * hwt * ga);
+                if ((unsigned)o.y != kOob) fp_atomic_add(gvb + ((unsigned)o.y >> 2), hh * lw * ga);
+                if ((unsigned)o.z != kOob) fp_atomic_add(gvb + ((unsigned)o.z >> 2), lh * hwt * ga);
+                if ((unsigned)o.w != kOob) fp_atomic_add(gvb + ((unsigned)o.w >> 2), lh * lw * ga);
+                continue;
+            }
             // d_i = grad_out[c] * v_i[c]; corners outside the level read as zero (buffer bounds check)
             const float d1 = go * buf_ld1(vr, (unsigned)o.x + lane_b), d2 = go * buf_ld1(vr, (unsigned)o.y + lane_b);
             const float d3 = go * buf_ld1(vr, (unsigned)o.z + lane_b), d4 = go * buf_ld1(vr, (unsigned)o.w + lane_b);
@@ -378,6 +387,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
             if (c == 16) rp[k] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, a);
         }
     }
+    if (SCATTER_ONLY) return;
     __syncthreads();
 
     // ---- coalesced write-back of grad_attn_weight / grad_sampling_loc --------------------------

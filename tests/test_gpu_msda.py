@@ -85,7 +85,7 @@ def _random_case(seed, shapes, N, M, D, Lq, P, dtype, wide=True):
     return value, shapes, loc.astype(dtype), attn.astype(dtype), gout.astype(dtype)
 
 
-@pytest.mark.parametrize("variants", [(1, 8), (2, 32), (4, 8), (99, 99)])
+@pytest.mark.parametrize("variants", [(1, 8), (2, 32), (4, 8), (99, 99), (1, 808), (2, 832), (0, 0)])
 @pytest.mark.parametrize("Lq", [1, 7, 8, 9, 31, 32, 33, 300])
 def test_fast_path_variants_vs_oracle(variants, Lq):
     """Every forced kernel variant of the fp32 / D=32 path (forward split 1/2/4, backward 8/32 rows per
@@ -122,7 +122,7 @@ def test_fast_path_generic_heads_levels_points(M, L, P):
     ([(17, 9)], 3, 1, "near"),                                  # single level, ragged patches, odd head count
     ([(9, 33), (5, 17), (3, 9), (2, 5), (1, 3)], 8, 4, "wide"), # five levels, samples partly outside
 ])
-@pytest.mark.parametrize("variant", [(0, 0), (1, 32), (408, 64), (216, 65), (804, 66), (0, 67), (500, 70), (500, 71)])
+@pytest.mark.parametrize("variant", [(0, 0), (1, 32), (2, 832), (408, 64), (216, 65), (804, 66), (0, 67), (500, 70), (500, 71)])
 def test_encoder_self_attention_vs_oracle(shapes, M, P, mode, variant):
     """num_query == spatial_size selects the patch-tiled forward and (with num_point == 4) the gather +
     owner-computes scatter backward (variant 0); (1, 32) forces the plain kernels on the same inputs; the
