@@ -118,6 +118,10 @@ int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const 
  * profiler prints their base names), so that a benchmark reports what actually ran instead of a hand-kept table. */
 const char *semidetr_msda_last_kernels(void);
 
+/* Tuning aid: per-phase cycle counters of the instrumented destination-owned kernel (set_variant(.., 73)); host
+ * array of 16 values; reset != 0 zeroes the device counters after reading. */
+int semidetr_debug_counters(unsigned long long *out16, int reset);
+
 /* Measurement aid: float4 streaming copy of `numel` fp32 values (multiple of 4, 16-byte aligned) -- the best
  * streaming rate of the box is what bench.py quotes `frac_hbm_measured` against. */
 int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel, int nontemporal);

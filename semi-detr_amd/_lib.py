@@ -36,6 +36,7 @@ SIGNATURES = {
     "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 2 + [c_int] * 8 + [c_void_p] * 3),
     "semidetr_msda_set_variant": (None, [c_int, c_int]),
     "semidetr_msda_last_kernels": (ctypes.c_char_p, []),
+    "semidetr_debug_counters": (c_int, [c_void_p, c_int]),
     "semidetr_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
     "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),

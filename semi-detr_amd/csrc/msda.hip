@@ -490,7 +490,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || (g_bwd_variant >= 64 && g_bwd_variant <= 73)) {
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || (g_bwd_variant >= 64 && g_bwd_variant <= 74)) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
@@ -514,13 +514,19 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         }
         // grad_value: destination-owned tiles (msda_dest.h) unless a windowed variant is forced (64..67) or the pyramid
         // has more levels than the kernel's LDS tables hold
-        if (L <= kDestMaxLevels && g_bwd_variant >= 70 && g_bwd_variant <= 73) {
+        if (L <= kDestMaxLevels && g_bwd_variant >= 70 && g_bwd_variant <= 74) {
             // grid sizing hint: about 2.5 units per 256 rows of a usual 4-level pyramid (coarse tiles are split);
             // workgroups take units slot, slot + bound, ... so any bound >= 1 is correct
             const int bound = (S / 256 + 1) * 3 + 64;
             const int64_t grid = (int64_t)N * bound * M;
             SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
-            if (g_bwd_variant == 72)
+            if (g_bwd_variant == 74)
+                hipLaunchKernelGGL((msda_bwd_dest_d32<IO, 16, 16, 8, 3>), dim3((unsigned)grid), dim3(kDestThreads), 0, st,
+                                   grad_out, spatial_shapes, level_start, io, S, M, L, P, bound, grad_value);
+            else if (g_bwd_variant == 73)
+                hipLaunchKernelGGL((msda_bwd_dest_d32<IO, 16, 16, 8, 2>), dim3((unsigned)grid), dim3(kDestThreads), 0, st,
+                                   grad_out, spatial_shapes, level_start, io, S, M, L, P, bound, grad_value);
+            else if (g_bwd_variant == 72)
                 hipLaunchKernelGGL((msda_bwd_dest_d32<IO, 16, 16, 8, 1>), dim3((unsigned)grid), dim3(kDestThreads), 0, st,
                                    grad_out, spatial_shapes, level_start, io, S, M, L, P, bound, grad_value);
             else if (g_bwd_variant == 71)
@@ -566,6 +572,18 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
 }  // namespace
 
 extern "C" const char *semidetr_msda_last_kernels(void) { return g_last_kernels; }
+
+// tuning aid: per-phase cycle counters of the instrumented destination-owned kernel (variant 73); reset = 1 zeroes them
+extern "C" int semidetr_debug_counters(unsigned long long *out16, int reset)
+{
+    hipError_t e = hipSuccess;
+    if (out16) e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dest_dbg), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_dest_dbg), z, sizeof(z));
+    }
+    return e == hipSuccess ? SEMIDETR_OK : semidetr::fail((int)e, "debug_counters: %s", hipGetErrorString(e));
+}
 
 extern "C" void semidetr_msda_set_variant(int fwd_variant, int bwd_variant)
 {

@@ -32,6 +32,8 @@
 #pragma once
 
 constexpr int kDestThreads = 512;
+// instrumented build (DBG == 2): per-phase cycle counts summed over workgroups, read back by semidetr_debug_counters
+__device__ unsigned long long g_dest_dbg[16];
 constexpr int kDestMaxLevels = 8;        // LDS tables of the kernel (pyramids with more levels take the windowed kernel)
 
 template <typename IO, int TH, int TW, int R, int DBG = 0>
@@ -40,15 +42,18 @@ __global__ __launch_bounds__(kDestThreads, 4) void msda_bwd_dest_d32(
     const IO io, int S, int M, int L, int P, int units_bound, float *__restrict__ gvalue)
 {
     constexpr int NT = kDestThreads, EMAX = 2048, BATCH = 1024, CAPS = 8192, MISSMAX = 128, ML = kDestMaxLevels;
-    constexpr int kRows = TH * TW, CW = TW + 1, kCells = (TH + 1) * CW;
+    // cells (top-left corners) iy in [0, TH], ix in [0, TW] (tile-local corner + 1), numbered COLOUR-MAJOR: colour =
+    // (iy & 1) * 2 + (ix & 1); cells of one colour have disjoint 2 x 2 footprints and are contiguous in the sorted list
+    constexpr int kRows = TH * TW, NXC = (TW + 2) / 2, CC = NXC * ((TH + 2) / 2), kCells = 4 * CC;
     static_assert(kCells <= NT, "the scan gives one cell counter to each thread");
+    static_assert(EMAX <= 0x8000, "order[] keeps the first-of-cell flag in bit 15");
     static_assert(EMAX % NT == 0 && BATCH % NT == 0 && BATCH <= EMAX, "whole iterations");
     static_assert((TW & (TW - 1)) == 0, "row -> (y, x) by shifts");
     __shared__ float acc[kRows * kD];                 // the tile of grad_value rows being built
     __shared__ float4 ent[EMAX];                      // kept samples {lw, lh, attention, bits(query)}
     __shared__ unsigned short cellid[EMAX], order[EMAX];
     __shared__ float4 miss[MISSMAX];                  // out-of-reach corners {weight, bits(query), bits(pixel), -}
-    __shared__ int cnt[kCells], start[kCells];
+    __shared__ int cnt[kCells], start[kCells + 1];
     __shared__ unsigned char touched[kRows];
     __shared__ int lv_h[ML], lv_w[ML], lv_st[ML], lv_units[ML], lv_splits[ML];
     __shared__ int rect[ML][4], pre[ML + 1];          // candidate rectangle / sample prefix per query level
@@ -115,10 +120,22 @@ __global__ __launch_bounds__(kDestThreads, 4) void msda_bwd_dest_d32(
         }
         __syncthreads();
         const int c_lo = split * CAPS, c_hi = min(pre[L], c_lo + CAPS);
+        unsigned long long tmark = DBG >= 2 ? __builtin_readcyclecounter() : 0ull;
         const float inv_p = 1.0f / (float)P;
 
         // one sort + accumulate round over the `ne` samples listed so far
+        auto lap = [&](int slot_) {
+            if (DBG >= 2 && tid == 0) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                atomicAdd(&g_dest_dbg[slot_], now - tmark);
+                tmark = now;
+            } else if (DBG >= 2) {
+                tmark = 0;
+            }
+        };
         auto round = [&](int ne) {
+            lap(0);                  // 0: enumeration since the last lap
+            if (DBG >= 2 && tid == 0) { atomicAdd(&g_dest_dbg[8], 1ull); atomicAdd(&g_dest_dbg[9], (unsigned long long)ne); }
             if (DBG == 1) {          // timing aid: enumeration only
                 __syncthreads();
                 if (tid == 0) ctl[3] = 0;
@@ -147,57 +164,90 @@ __global__ __launch_bounds__(kDestThreads, 4) void msda_bwd_dest_d32(
                 int base = 0;
                 for (int w2 = 0; w2 < wv; ++w2) base += wsum[w2];
                 if (tid < kCells) start[tid] = base + incl - v;
+                if (tid == 0) start[kCells] = ne;
             }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < EMAX / NT; ++i) {
                 const int e = tid + i * NT;
-                if (e < ne) order[start[cellid[e]] + rk[i]] = (unsigned short)e;
+                if (e < ne) order[start[cellid[e]] + rk[i]] = (unsigned short)(e | (rk[i] == 0 ? 0x8000 : 0));
             }
             __syncthreads();
-            // ---- accumulate: four colour classes of cells with disjoint 2 x 2 footprints
-#pragma unroll
-            for (int col = 0; col < 4; ++col) {
-                const int py = col >> 1, px = col & 1;
-                const int ny = (TH - py) / 2 + 1, nx = (TW - px) / 2 + 1;      // cells iy = py, py+2, .. <= TH
-                for (int k = hw; k < ny * nx; k += NT / 32) {
-                    const int iy = py + 2 * (k / nx), ix = px + 2 * (k % nx);
-                    const int cell = iy * CW + ix;
-                    const int nn = cnt[cell];
-                    if (nn == 0) continue;
-                    const int s0 = start[cell];
-                    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-                    auto add = [&](const float4 &en, float g) {
-                        const float hh = 1.f - en.y, hwt = 1.f - en.x;
-                        const float t = en.z * g, tt = hh * t, tb = en.y * t;
-                        a00 += tt * hwt; a01 += tt * en.x; a10 += tb * hwt; a11 += tb * en.x;
+            lap(1);                  // 1: counting sort
+            // ---- accumulate.  64 groups of 8 lanes (lane j = channels 4j..4j+3) each take an equal share of the
+            //      colour's sorted entries -- snapped to cell boundaries: a group owns the cells whose FIRST entry lies in
+            //      its share -- and stream through them eight at a time (8 entry reads, then 8 independent grad_out row
+            //      loads in flight, then the short dependent chain), keeping the four corner sums of the current cell in
+            //      registers and adding them to the LDS tile when the cell ends.  Cells of one colour have disjoint
+            //      footprints, so the read-modify-write needs no atomics; a barrier separates the colours.
+            {
+                constexpr int G = NT / 8;
+                const int grp = tid >> 3, j = tid & 7;
+                const float4 *gb4 = reinterpret_cast<const float4 *>(gout + ((int64_t)n * Lq * M + m) * kD) + j;
+                const int rs4 = rs / 4;
+                float4 *acc4 = reinterpret_cast<float4 *>(acc) + j;
+#pragma unroll 1
+                for (int col = 0; col < 4; ++col) {
+                    const int e0 = start[col * CC], e1 = start[(col + 1) * CC];
+                    const int len = e1 - e0;
+                    int i = e0 + (int)((int64_t)len * grp / G);
+                    const int hi = e0 + (int)((int64_t)len * (grp + 1) / G);
+                    while (i < e1 && !(order[i] & 0x8000)) ++i;      // tail of a cell that belongs to the previous share
+                    float4 a00 = make_float4(0.f, 0.f, 0.f, 0.f), a01 = a00, a10 = a00, a11 = a00;
+                    int cur = -1;
+                    auto deposit = [&]() {
+                        if (cur < 0) return;
+                        const int idx = cur - col * CC;
+                        const int cy = 2 * (idx / NXC) + (col >> 1) - 1, cx = 2 * (idx % NXC) + (col & 1) - 1;
+                        const bool y0 = (unsigned)cy < (unsigned)TH, y1 = (unsigned)(cy + 1) < (unsigned)TH;
+                        const bool x0 = (unsigned)cx < (unsigned)TW, x1 = (unsigned)(cx + 1) < (unsigned)TW;
+                        const int r00 = cy * TW + cx;
+                        auto rmw = [&](int r, const float4 &a) {
+                            float4 v = acc4[r * 8];
+                            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                            acc4[r * 8] = v;
+                            if (j == 0) touched[r] = 1;
+                        };
+                        if (y0 && x0) rmw(r00, a00);
+                        if (y0 && x1) rmw(r00 + 1, a01);
+                        if (y1 && x0) rmw(r00 + TW, a10);
+                        if (y1 && x1) rmw(r00 + TW + 1, a11);
+                        a00 = a01 = a10 = a11 = make_float4(0.f, 0.f, 0.f, 0.f);
                     };
-                    int i = 0;
-                    for (; i + 4 <= nn; i += 4) {
-                        float4 en[4];
-                        float g[4];
+                    bool done = i >= hi;
+                    while (!done && i < e1) {
+                        unsigned short o[8];
+                        float4 g[8];
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) en[q4] = ent[order[s0 + i + q4]];
+                        for (int u = 0; u < 8; ++u) o[u] = order[min(i + u, e1 - 1)];
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) g[q4] = gb[(int64_t)__float_as_int(en[q4].w) * rs];
+                        for (int u = 0; u < 8; ++u)      // only the query index is needed before the loads are issued
+                            g[u] = DBG == 3 ? make_float4(1.f, 1.f, 1.f, 1.f)       // timing aid: no grad_out loads
+                                            : gb4[(int64_t)__float_as_int(ent[o[u] & 0x7fff].w) * rs4];
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) add(en[q4], g[q4]);
+                        for (int u = 0; u < 8; ++u) {
+                            if (done || i + u >= e1) { done = true; continue; }
+                            if (o[u] & 0x8000) {
+                                if (i + u >= hi) { done = true; continue; }
+                                deposit();
+                                cur = cellid[o[u] & 0x7fff];
+                            }
+                            const float4 en = ent[o[u] & 0x7fff];
+                            const float lw = en.x, lh = en.y, a = en.z;
+                            const float hh = 1.f - lh, hwt = 1.f - lw;
+                            const float w1 = hh * hwt * a, w2 = hh * lw * a, w3 = lh * hwt * a, w4 = lh * lw * a;
+                            a00.x += w1 * g[u].x; a00.y += w1 * g[u].y; a00.z += w1 * g[u].z; a00.w += w1 * g[u].w;
+                            a01.x += w2 * g[u].x; a01.y += w2 * g[u].y; a01.z += w2 * g[u].z; a01.w += w2 * g[u].w;
+                            a10.x += w3 * g[u].x; a10.y += w3 * g[u].y; a10.z += w3 * g[u].z; a10.w += w3 * g[u].w;
+                            a11.x += w4 * g[u].x; a11.y += w4 * g[u].y; a11.z += w4 * g[u].z; a11.w += w4 * g[u].w;
+                        }
+                        i += 8;
                     }
-                    for (; i < nn; ++i) {
-                        const float4 en = ent[order[s0 + i]];
-                        add(en, gb[(int64_t)__float_as_int(en.w) * rs]);
-                    }
-                    const int cy = iy - 1, cx = ix - 1;                     // tile-local top-left corner
-                    const bool y0 = (unsigned)cy < (unsigned)TH, y1 = (unsigned)(cy + 1) < (unsigned)TH;
-                    const bool x0 = (unsigned)cx < (unsigned)TW, x1 = (unsigned)(cx + 1) < (unsigned)TW;
-                    const int r00 = cy * TW + cx;
-                    if (y0 && x0) { acc[r00 * kD + c] += a00; if (c == 0) touched[r00] = 1; }
-                    if (y0 && x1) { acc[(r00 + 1) * kD + c] += a01; if (c == 0) touched[r00 + 1] = 1; }
-                    if (y1 && x0) { acc[(r00 + TW) * kD + c] += a10; if (c == 0) touched[r00 + TW] = 1; }
-                    if (y1 && x1) { acc[(r00 + TW + 1) * kD + c] += a11; if (c == 0) touched[r00 + TW + 1] = 1; }
+                    deposit();
+                    __syncthreads();
                 }
-                __syncthreads();
             }
+            lap(2);                  // 2: walk + read-modify-write, four colours
             // ---- out-of-reach corners: one full-line atomic each, exactly like the plain kernel
             const int nmiss = min(ctl[3], MISSMAX);
             for (int mi = hw; mi < nmiss; mi += NT / 32) {
@@ -206,8 +256,10 @@ __global__ __launch_bounds__(kDestThreads, 4) void msda_bwd_dest_d32(
                 fp_atomic_add(gvb + (int64_t)__float_as_int(ms.z) * rs, ms.x * g);
             }
             __syncthreads();
+            if (DBG >= 2 && tid == 0) atomicAdd(&g_dest_dbg[10], (unsigned long long)nmiss);
             if (tid == 0) ctl[3] = 0;
             __syncthreads();
+            lap(3);                  // 3: misses
         };
 
         // The list position of a kept sample = samples listed before this batch (`ne`, a register every thread keeps in
@@ -260,7 +312,7 @@ __global__ __launch_bounds__(kDestThreads, 4) void msda_bwd_dest_d32(
                                 if (mine) {
                                     push = true;
                                     en = make_float4(lw, lh, a, __int_as_float(q));
-                                    cell = (cy + 1) * CW + (cx + 1);
+                                    cell = (((cy + 1) & 1) * 2 + ((cx + 1) & 1)) * CC + ((cy + 1) >> 1) * NXC + ((cx + 1) >> 1);
                                 }
                                 if (home) {      // corners nobody else will pick up
                                     const float hh = 1.f - lh, hwt = 1.f - lw;
@@ -311,11 +363,14 @@ __global__ __launch_bounds__(kDestThreads, 4) void msda_bwd_dest_d32(
             }
         }
 
+        lap(4);                      // 4: tail of the unit loop (nothing)
         // ---- flush: every touched row of the tile once
         for (int r = hw; r < kRows; r += NT / 32) {
             const int y = r / TW, x = r % TW;
             if (y < THc && x < TWc && touched[r])
                 fp_atomic_add(gvb + (int64_t)(st + (ty0 + y) * W + tx0 + x) * rs, acc[r * kD + c]);
         }
+        lap(5);                      // 5: flush
+        if (DBG >= 2 && tid == 0) atomicAdd(&g_dest_dbg[11], 1ull);     // units
     }
 }

@@ -43,8 +43,11 @@ def _check(out, gv, o_out, o_gv):
 
 @pytest.fixture(autouse=True)
 def _auto_variant():
+    import os
     import semi_detr_amd
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, 0)
+    # SEMIDETR_TEST_VARIANT="fwd,bwd" runs the same full-size parity checks on a forced kernel variant (tuning aid)
+    fv, bv = [int(x) for x in os.environ.get("SEMIDETR_TEST_VARIANT", "0,0").split(",")]
+    semi_detr_amd._lib.lib().semidetr_msda_set_variant(fv, bv)
     yield
     semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, 0)
 

@@ -1,0 +1,21 @@
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+import semi_detr_amd as sda
+import MultiScaleDeformableAttention as MSDA
+lib = sda._lib.lib()
+dev = torch.device("cuda:0")
+wl_shapes = torch.as_tensor(bench.LEVELS, dtype=torch.long, device=dev)
+v, sh, st, loc, attn, gout, Sx, Lx, lq = bench._msda_case(dev, bench.LEVELS, 4, 0, True)
+gout = torch.rand_like(gout)
+lib.semidetr_msda_set_variant(0, int(sys.argv[1]) if len(sys.argv) > 1 else 73)
+buf = (ctypes.c_ulonglong * 16)()
+MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, gout, 64); torch.cuda.synchronize()
+lib.semidetr_debug_counters(ctypes.cast(buf, ctypes.c_void_p), 1)
+MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, gout, 64); torch.cuda.synchronize()
+lib.semidetr_debug_counters(ctypes.cast(buf, ctypes.c_void_p), 1)
+names = ["enumerate", "sort", "walk", "misses", "tail", "flush", "", "", "rounds", "entries", "misses_n", "units"]
+tot = sum(buf[i] for i in range(6))
+for i, nme in enumerate(names):
+    if nme: print(f"{nme:10s} {buf[i]:16d}" + (f"  {100.0*buf[i]/tot:5.1f}% of workgroup cycles" if i < 6 else ""))
+print("entries/round", buf[9] / max(1, buf[8]), "rounds/unit", buf[8] / max(1, buf[11]), "cycles/round", tot / max(1, buf[8]))
