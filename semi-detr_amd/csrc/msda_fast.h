@@ -973,3 +973,225 @@ __global__ __launch_bounds__(512, 4) void msda_fwd_d32_res(
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// grad_value for ARBITRARY query sets (decoder cross-attention, the BASELINE micro-benchmark shape), fp32, D == 32,
+// with the coarse levels pre-aggregated in LDS.  Runs after msda_bwd_gather_d32 (which produces the two small gradients).
+//
+// The plain backward issues one full-row atomic per (sample, corner) and sits exactly on the atomic unit's ceiling
+// (10.4 G rows/s: 307 k rows = 29.5 us at the micro-benchmark shape, 2.25 M rows = 216 us for the bs-4 decoder).  But
+// the queries of one (image, head) throw Lq * P samples at EVERY level, and the coarse levels are small: 300 queries x 4
+// points x 4 corners = 4800 contributions land on the 273 rows of a 13 x 21 level.  So a workgroup takes (image, head,
+// level, chunk of <= 256 queries), stages the chunk's grad_out rows in LDS, and
+//   * level with <= kLvlRows pixels: buckets the (sample, corner) pairs by target row with integer LDS atomics (count ->
+//     scan -> fill, as the windowed kernel does, the "window" being the whole level), lets 32 streams of 16 lanes walk
+//     equal shares of the row-sorted entries with the row sum in registers, and issues ONE full-line atomic per row run;
+//   * larger level: the same walk over the unsorted entries, every entry flushed on its own (= the plain kernel).
+// Rows flushed, micro-benchmark shape: 19.2 k -> ~9 k per (image, head).
+// ---------------------------------------------------------------------------------------------
+constexpr int kLvlThreads = 512;
+constexpr int kLvlQ = 256;               // queries per workgroup
+constexpr int kLvlRows = 4352;           // largest level that is bucketed (counters: 2 x 17 KB of LDS)
+
+template <typename IO>
+__global__ __launch_bounds__(kLvlThreads) void msda_bwd_scatter_d32_lvl(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts, const IO io,
+    int S, int M, int L, int Lq, int P, int chunks, int chunk_q, float *__restrict__ gvalue)
+{
+    constexpr int NT = kLvlThreads, kStreams = NT / 16;
+    extern __shared__ float4 smem[];
+    // layout: gtile [kLvlQ * 32 floats] | entries [emax float2] | cnt [kLvlRows] | start [kLvlRows]
+    float *gtile = reinterpret_cast<float *>(smem);
+    float2 *entries = reinterpret_cast<float2 *>(gtile + kLvlQ * kD);
+    const int emax = chunk_q * P * 4;
+    int *cnt = reinterpret_cast<int *>(entries + emax + 8);
+    int *start = cnt + kLvlRows;
+    __shared__ int wsum[NT / 64], total_s;
+
+    const int LP = L * P, rs = M * kD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hw = tid >> 5, c = tid & 31;
+    // block -> (chunk, level, head, image): heads fastest (XCD = head), levels next so that the four levels of a chunk
+    // (different amounts of work) are spread over the launch
+    int b = blockIdx.x;
+    const int m = b % M; b /= M;
+    const int l = b % L; b /= L;
+    const int ch = b % chunks, n = b / chunks;
+    const int q0 = ch * chunk_q, nq = min(chunk_q, Lq - q0);
+    if (nq <= 0) return;
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+    const int R = H * W;
+    const bool bucket = R <= kLvlRows;
+
+    {   // grad_out rows of the chunk -> LDS, channels (c, c+16) interleaved; all loads of a thread are issued before its
+        // stores (a load -> store loop would expose the global latency once per row)
+        constexpr int kPass = kLvlQ * 8 / NT;               // float4 pieces per thread
+        float4 v[kPass];
+        const float4 *src = reinterpret_cast<const float4 *>(gout + (((int64_t)n * Lq + q0) * M + m) * kD);
+#pragma unroll
+        for (int ps = 0; ps < kPass; ++ps) {
+            const int r = (tid >> 3) + ps * (NT / 8);
+            v[ps] = r < nq ? src[(int64_t)r * (rs / 4) + (tid & 7)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int ps = 0; ps < kPass; ++ps) {
+            const int r = (tid >> 3) + ps * (NT / 8), c0 = 4 * (tid & 7);
+            if (r < nq) {
+                float *dst = gtile + r * kD;
+                dst[((c0 + 0) & 15) * 2 + ((c0 + 0) >> 4)] = v[ps].x;
+                dst[((c0 + 1) & 15) * 2 + ((c0 + 1) >> 4)] = v[ps].y;
+                dst[((c0 + 2) & 15) * 2 + ((c0 + 2) >> 4)] = v[ps].z;
+                dst[((c0 + 3) & 15) * 2 + ((c0 + 3) >> 4)] = v[ps].w;
+            }
+        }
+    }
+    if (bucket)
+        for (int k = tid; k < R; k += NT) cnt[k] = 0;
+    if (tid == 0) total_s = 0;
+
+    // ---- geometry of this thread's samples (query i, point p), sample index tid + sp * NT: every global load first,
+    //      then the arithmetic (so the SPT samples' latencies overlap instead of adding up)
+    constexpr int SPT = (kLvlQ * 8 + NT - 1) / NT;           // up to 8 points per query
+    float cw[SPT][4];
+    int crow[SPT][4], rank[SPT][4], qi[SPT];
+    const int nsamp = nq * P;
+    float sx[SPT], sy[SPT], sa[SPT];
+#pragma unroll
+    for (int sp = 0; sp < SPT; ++sp) {
+        const int sidx = min(tid + sp * NT, nsamp - 1);      // clamped: the loads stay unconditional
+        const int i = sidx / P, p = sidx - i * P;
+        const int64_t nqi = (int64_t)n * Lq + q0 + i, row = nqi * M + m;
+        const int k = l * P + p;
+        io.load_xy(row, nqi, LP, k, l, P, H, W, sx[sp], sy[sp]);
+        sa[sp] = io.load_w(row, LP, k);
+        if (IO::kSoftmax) {
+            float mx = sa[sp];
+            for (int j = 0; j < LP; ++j) mx = fmaxf(mx, io.load_w(row, LP, j));
+            float sum = 0.f;
+            for (int j = 0; j < LP; ++j) sum += expf(io.load_w(row, LP, j) - mx);
+            sa[sp] = expf(sa[sp] - mx) / sum;
+        }
+    }
+#pragma unroll
+    for (int sp = 0; sp < SPT; ++sp) {
+        const int sidx = tid + sp * NT;
+        qi[sp] = -1;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) { crow[sp][ci] = -1; cw[sp][ci] = 0.f; rank[sp][ci] = 0; }
+        int off[4];
+        float lw, lh;
+        if (sidx >= nsamp || !sample_setup(sx[sp], sy[sp], H, W, 0, 1, off, lw, lh)) continue;   // off = level-local pixel or -1
+        const float a = sa[sp];
+        const float hh = 1.f - lh, hwt = 1.f - lw;
+        cw[sp][0] = hh * hwt * a; cw[sp][1] = hh * lw * a; cw[sp][2] = lh * hwt * a; cw[sp][3] = lh * lw * a;
+        qi[sp] = sidx / P;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) crow[sp][ci] = off[ci];
+    }
+    __syncthreads();                     // counters zeroed, grad_out staged
+    // ---- position of every (sample, corner) entry
+    if (bucket) {
+#pragma unroll
+        for (int sp = 0; sp < SPT; ++sp)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+                if (crow[sp][ci] >= 0) rank[sp][ci] = atomicAdd(&cnt[crow[sp][ci]], 1);
+        __syncthreads();
+        // exclusive scan of R counters: thread t owns counters [t * K, t * K + K)
+        const int K = (R + NT - 1) / NT;
+        int local = 0;
+        for (int k = tid * K; k < min(R, tid * K + K); ++k) local += cnt[k];
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+        int run = base + incl - local;
+        for (int k = tid * K; k < min(R, tid * K + K); ++k) { start[k] = run; run += cnt[k]; }
+        if (tid == NT - 1) total_s = run;
+        __syncthreads();
+#pragma unroll
+        for (int sp = 0; sp < SPT; ++sp)
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                const int r = crow[sp][ci];
+                if (r >= 0)
+                    entries[start[r] + rank[sp][ci]] = make_float2(
+                        cw[sp][ci], __int_as_float((rank[sp][ci] == cnt[r] - 1 ? (1 << 30) : 0) | (r << 10) | qi[sp]));
+            }
+    } else {        // level too large to bucket: unsorted list, every entry is the last of its row
+#pragma unroll
+        for (int sp = 0; sp < SPT; ++sp) {
+            int nv = 0;
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) nv += crow[sp][ci] >= 0;
+            // wave-aggregated append
+            int incl = nv;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            int wbase = 0;
+            if (lane == 63 && incl) wbase = atomicAdd(&total_s, incl);
+            wbase = __shfl(wbase, 63, 64);
+            int pos = wbase + incl - nv;
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+                if (crow[sp][ci] >= 0)
+                    entries[pos++] = make_float2(cw[sp][ci], __int_as_float((1 << 30) | (crow[sp][ci] << 10) | qi[sp]));
+        }
+    }
+    __syncthreads();
+    // ---- walk: 32 streams of 16 lanes (lane = channels l16 and l16 + 16), equal shares, one atomic pair per row run
+    {
+        const int sid = tid >> 4, l16 = tid & 15;
+        const float2 *gt2 = reinterpret_cast<const float2 *>(gtile);
+        float *gvs = gvalue + (((int64_t)n * S + st) * M + m) * kD + l16;
+        const int total = total_s;
+        const int lo = (int)((int64_t)total * sid / kStreams), hi = (int)((int64_t)total * (sid + 1) / kStreams);
+        int cur = -1;
+        float2 accv = make_float2(0.f, 0.f);
+        auto flush = [&](int rowi) {
+            float *pr = gvs + (int64_t)rowi * rs;
+            fp_atomic_add(pr, accv.x);
+            fp_atomic_add(pr + 16, accv.y);
+        };
+        auto step = [&](const float2 &en, const float2 &gq) {
+            const int pk = __float_as_int(en.y);
+            accv.x += en.x * gq.x;
+            accv.y += en.x * gq.y;
+            cur = (pk >> 10) & 0xfffff;
+            if (pk & (1 << 30)) {
+                flush(cur);
+                accv = make_float2(0.f, 0.f);
+                cur = -1;
+            }
+        };
+        int e = lo;
+        for (; e + 8 <= hi; e += 8) {
+            float2 en[8], gq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) en[u] = entries[e + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 1023) * 16 + l16];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) step(en[u], gq[u]);
+        }
+        if (e < hi) {
+            float2 en[8], gq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) en[u] = entries[min(e + u, hi - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 1023) * 16 + l16];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e + u < hi) step(en[u], gq[u]);
+        }
+        if (cur >= 0) flush(cur);
+    }
+}

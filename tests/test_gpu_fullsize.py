@@ -15,6 +15,7 @@ import pytest
 import torch
 
 import oracle
+from conftest import kink_mask
 from test_gpu_fused import _prologue_np
 
 pytestmark = pytest.mark.gpu
@@ -95,7 +96,10 @@ def test_encoder_bs4_full_size_vs_oracle(io):
     want_off = (o_gl.astype(np.float64) / norm).astype(np.float32)
     a64, g64 = attn.astype(np.float64).reshape(N, -1, M, 16), o_ga.astype(np.float64).reshape(N, -1, M, 16)
     want_log = (a64 * (g64 - (a64 * g64).sum(-1, keepdims=True))).astype(np.float32)
-    np.testing.assert_allclose(goff.cpu().numpy(), want_off, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want_off).max())))
+    # the kernel forms the location in fp32, the numpy prologue in fp64: a sample within rounding of a pixel-centre line
+    # can fall on the other side of the kink of the bilinear interpolant (one-sided derivative) -> excluded, see conftest
+    ok = ~kink_mask(loc, shp)
+    np.testing.assert_allclose(goff.cpu().numpy()[ok], want_off[ok], rtol=0, atol=1e-4 * max(1.0, float(np.abs(want_off).max())))
     np.testing.assert_allclose(glog.cpu().numpy(), want_log, rtol=0, atol=2e-5)
 
 
@@ -141,3 +145,41 @@ def test_decoder_full_size_vs_oracle(name, levels, N, Lq):
     _check(out.cpu().numpy(), gv.cpu().numpy(), o_out, o_gv)
     np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
     np.testing.assert_allclose(gl.cpu().numpy(), o_gl, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gl).max())))
+
+
+@pytest.mark.parametrize("ref_dim", [4, 2])
+def test_decoder_fused_full_size_vs_oracle(ref_dim):
+    """The fused prologue / epilogue (RawIO) at decoder size, bs 4, Lq = 1100 -- the launch size that takes the gather +
+    level-aggregated scatter pair (msda_bwd_scatter_d32_lvl) -- against the oracle on a numpy prologue."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd  # noqa: F401
+    N, Lq, L = 4, 1100, 4
+    rng = np.random.default_rng(40 + ref_dim)
+    shp = np.asarray(LEVELS, np.int64)
+    S = int((shp[:, 0] * shp[:, 1]).sum())
+    ref = rng.random((N, Lq, L, ref_dim)).astype(np.float32)
+    if ref_dim == 4:
+        ref[..., 2:] = ref[..., 2:] * 0.3 + 0.02
+    off = (rng.standard_normal((N, Lq, M, L, P, 2)) * (1.5 if ref_dim == 4 else 6.0)).astype(np.float32)
+    logits = (rng.standard_normal((N, Lq, M, L * P)) * 2).astype(np.float32)
+    value = (rng.random((N, S, M, D)) * 0.01).astype(np.float32)
+    gout = rng.random((N, Lq, M * D)).astype(np.float32)
+    loc, attn = _prologue_np(ref, off, logits, shp, P)
+    o_out = oracle.msda_forward(value, shp, loc, attn)
+    o_gv, o_gl, o_ga = oracle.msda_backward(value, shp, loc, attn, gout, parallel=True)
+    tsh = _t(shp)
+    tls = _starts(tsh)
+    out = MSDA.ms_deform_attn_fused_forward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits))
+    gv, goff, glog = MSDA.ms_deform_attn_fused_backward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits), _t(gout))
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), gv.cpu().numpy(), o_out, o_gv)
+    if ref_dim == 2:
+        scale = 1.0 / np.stack([shp[:, 1], shp[:, 0]], -1).astype(np.float64)[None, None, None, :, None, :]
+    else:
+        scale = 0.5 * ref[:, :, None, :, None, 2:].astype(np.float64) / P
+    want_off = (o_gl.astype(np.float64) * scale).astype(np.float32)
+    a64, g64 = attn.astype(np.float64).reshape(N, Lq, M, 16), o_ga.astype(np.float64).reshape(N, Lq, M, 16)
+    want_log = (a64 * (g64 - (a64 * g64).sum(-1, keepdims=True))).astype(np.float32)
+    ok = ~kink_mask(loc, shp)      # see test_encoder_bs4_full_size_vs_oracle
+    np.testing.assert_allclose(goff.cpu().numpy()[ok], want_off[ok], rtol=0, atol=1e-4 * max(1.0, float(np.abs(want_off).max())))
+    np.testing.assert_allclose(glog.cpu().numpy(), want_log, rtol=0, atol=2e-5)
