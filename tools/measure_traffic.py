@@ -29,6 +29,7 @@ GROUPS = [  # bench group name, probe arguments
     ("msda_bwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "bwd"]),
     ("msda_fwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "fwd"]),
     ("msda_bwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "bwd"]),
+    ("msda_bwd_dec_bs1_Lq1100", ["--shape", "dec", "--bs", "1", "--lq", "1100", "--dir", "bwd"]),
     ("msda_fwd_micro_bs2_Lq300", ["--shape", "micro", "--bs", "2", "--dir", "fwd"]),
     ("msda_bwd_micro_bs2_Lq300", ["--shape", "micro", "--bs", "2", "--dir", "bwd"]),
 ]
