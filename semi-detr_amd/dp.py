@@ -206,7 +206,7 @@ class FlatDDP(torch.nn.Module):
     """
 
     def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=False,
-                 find_unused_parameters=False, bucket_bytes=64 << 20, process_group=None):
+                 find_unused_parameters=False, bucket_bytes=64 << 20, process_group=None, _reduce_when_alone=False):
         super().__init__()
         if broadcast_buffers:
             raise NotImplementedError("FlatDDP: only broadcast_buffers=False (the reference's setting, "
@@ -215,6 +215,9 @@ class FlatDDP(torch.nn.Module):
         self.group = process_group
         self.find_unused_parameters = bool(find_unused_parameters)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # test aid: issue the collectives even in a one-rank group, so that the hook -> bucket -> RCCL all-reduce ->
+        # finalize path can run on a real RCCL communicator on a one-GPU box (tests/test_gpu_ema_pseudo.py)
+        self._alone = self.world == 1 and not (_reduce_when_alone and dist.is_initialized())
         self.require_backward_grad_sync = True
         self._sync_module_states()
         params = [p for p in module.parameters() if p.requires_grad]
@@ -231,13 +234,13 @@ class FlatDDP(torch.nn.Module):
             for b in bs:
                 self._bucket_need[b] += 1
         self._index = {id(p): i for i, p in enumerate(self.params)}
-        self._avg = (self.world > 1 and dist.get_backend(process_group) == "nccl")
+        self._avg = (dist.is_initialized() and dist.get_backend(process_group) == "nccl")
         self._reset()
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self.params]
 
     # -- construction-time state sync (torch DDP._sync_module_states): parameters and buffers from rank 0
     def _sync_module_states(self):
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             return
         with torch.no_grad():
             for t in list(self.module.parameters()) + list(self.module.buffers()):
@@ -258,7 +261,7 @@ class FlatDDP(torch.nn.Module):
             if p.grad is not None:                   # zero_grad(set_to_none=True) dropped the view: bring it home
                 view.copy_(p.grad)
             p.grad = view
-        if not self.require_backward_grad_sync or self.world == 1:
+        if not self.require_backward_grad_sync or self._alone:
             return
         if not self._callback_queued:
             self._callback_queued = True
@@ -308,12 +311,12 @@ class FlatDDP(torch.nn.Module):
                 self._fired[i] = True
                 for b in self._param_buckets[i]:
                     self._left[b] -= 1
-        if self.world > 1 and self.require_backward_grad_sync:
+        if not self._alone and self.require_backward_grad_sync:
             self._launch_ready()
 
     def finish(self):
         """Counterpart of ``mark_ready`` when no autograd engine callback runs."""
-        if self.world > 1 and self.require_backward_grad_sync:
+        if not self._alone and self.require_backward_grad_sync:
             self._finalize()
         else:
             self._reset()

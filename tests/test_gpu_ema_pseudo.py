@@ -187,6 +187,17 @@ def test_rccl_backend_initialises_and_reduces_on_this_gpu():
         "s = dp.ScalarReducer(torch.device('cuda', 0)); s.add(3.0); s.add(torch.tensor(5.0, device='cuda'))\n"
         "assert [float(v) for v in s.reduce_mean()] == [3.0, 5.0]\n"
         "assert float(g[999]) == 999.0\n"
+        # FlatDDP on the RCCL communicator: construction broadcast, autograd hooks -> bucketed all-reduce (ReduceOp.AVG on
+        # RCCL) -> finalize, and the manual mark_ready / finish drive bench.py uses
+        "net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 8)).cuda()\n"
+        "ddp = dp.FlatDDP(net, device_ids=[0], broadcast_buffers=False, bucket_bytes=16384, _reduce_when_alone=True)\n"
+        "assert ddp._avg and len(ddp.arena.buckets) > 2\n"
+        "x = torch.randn(16, 64, device='cuda')\n"
+        "ref = [torch.autograd.grad(net(x).square().sum(), list(net.parameters()))]\n"
+        "ddp.zero_grad(); ddp(x).square().sum().backward(); torch.cuda.synchronize()\n"
+        "for p, g0 in zip(net.parameters(), ref[0]): assert torch.allclose(p.grad, g0, rtol=1e-5, atol=1e-6)\n"
+        "ddp.zero_grad(); ddp.mark_ready(list(net.parameters())); ddp.finish(); torch.cuda.synchronize()\n"
+        "assert float(ddp.arena.flat.abs().sum()) == 0.0\n"
         "dist.destroy_process_group(); print('rccl ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
