@@ -323,9 +323,10 @@ def hbm_stream_peak(dev):
                                                     a.numel(), nt), "stream_copy")
 
     res = {}
-    bytes_per_call = {"ema_triad_2r1w": 3 * a.numel() * 4}
+    bytes_per_call = {"ema_triad_2r1w": 3 * a.numel() * 4, "own_float4_read_only": a.numel() * 4}
     for name, fn in (("own_float4_copy", lambda: own(0)), ("own_float4_copy_nt", lambda: own(1)),
-                     ("torch_copy", lambda: b.copy_(a)), ("ema_triad_2r1w", lambda: sda.ema_update_flat_(b, a, 0.5))):
+                     ("torch_copy", lambda: b.copy_(a)), ("ema_triad_2r1w", lambda: sda.ema_update_flat_(b, a, 0.5)),
+                     ("own_float4_read_only", lambda: own(2))):
         for _ in range(3):
             fn()
         best = 0.0
@@ -339,7 +340,9 @@ def hbm_stream_peak(dev):
             torch.cuda.synchronize()
             best = max(best, bytes_per_call.get(name, 2 * a.numel() * 4) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
         res[name] = best
-    return max(res.values()), res
+    # the denominator is the best rate of a kernel that READS AND WRITES (the MSDA launches do both); the read-only rate
+    # is reported beside it
+    return max(v for k, v in res.items() if k != "own_float4_read_only"), res
 
 
 def _msda_case(dev, levels, N, Lq, encoder):

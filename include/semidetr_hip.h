@@ -122,9 +122,10 @@ const char *semidetr_msda_last_kernels(void);
  * array of 16 values; reset != 0 zeroes the device counters after reading. */
 int semidetr_debug_counters(unsigned long long *out16, int reset);
 
-/* Measurement aid: float4 streaming copy of `numel` fp32 values (multiple of 4, 16-byte aligned) -- the best
- * streaming rate of the box is what bench.py quotes `frac_hbm_measured` against. */
-int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel, int nontemporal);
+/* Measurement aid: float4 streaming pass over `numel` fp32 values (multiple of 4, 16-byte aligned); mode 0 = copy,
+ * 1 = copy with nontemporal accesses, 2 = read only.  The best copy rate of the box is what bench.py quotes
+ * `frac_hbm_measured` against. */
+int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel, int mode);
 
 /* TEST / TUNING ONLY -- not part of the re-entrant contract above: forces a kernel variant of the f32 /
  * channels==32 fast path for every later call of the process (0 = automatic choice; codes in DESIGN.md 2.3b).

@@ -442,43 +442,43 @@ int launch_strips_backward(hipStream_t st, size_t fill, const float *grad_out, c
     // default: ONE kernel after the fill on the caller's stream.  The split below lost on MI355X (measured, r02): the
     // fork / join through events costs more than the 7-8 us of fill it hides -- micro-benchmark backward 42.8 -> 63.1 us,
     // decoder bs 4 242 -> 267 us, encoder bs 4 875 -> 893 us.  Kept selectable (808 / 832) as the evidence.
-    // level-aggregated scatter: default for launches with enough queries to fill the chip in chunks of <= 256 (measured:
-    // decoder bs 4 / Lq 1100 240 -> 175 us, bs 1 66 -> 55 us; the 300-query micro-benchmark shape gains nothing -- 128-256
-    // workgroups, 27 us scatter + 8 us gather against 35 us fused -- and keeps the single fused kernel)
-    if ((g_bwd_variant == 900 || (g_bwd_variant == 0 && (int64_t)N * Lq >= 1024)) && P <= 8) {
-        // fill, gather (the two small gradients), then the level-aggregated scatter
+    // level-aggregated scatter + gather in ONE merged launch: default for launches with at least 512 (image, query) pairs
+    // (measured: decoder bs 4 / Lq 1100 240 -> 163 us, bs 1 66 -> 54 us, BASELINE micro-benchmark shape 43.2 -> 39.7 us;
+    // as two launches -- gather, then scatter -- the micro-benchmark shape gained nothing: 8 + 27 us against 35 us fused)
+    if ((g_bwd_variant == 900 || (g_bwd_variant == 0 && (int64_t)N * Lq >= 512)) && P <= 8) {
+        // fill, then ONE launch: level-aggregated scatter workgroups + gather workgroups side by side
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
         if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-        const int gt = (Lq + 31) / 32;
-        const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
-        if (L * P == 16)
-            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
-                               grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
-        else
-            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
-                               grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
-        if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
-        // chunks of <= kLvlQ queries; small launches are cut finer so that about two workgroups per CU exist (more
-        // chunks = less aggregation per chunk, but a 128-workgroup launch leaves half the chip idle)
+        // chunks of <= kLvlQ queries; small launches are cut finer so that about one workgroup per CU exists
         int chunks = (Lq + kLvlQ - 1) / kLvlQ;
         const int want = (256 + N * L * M - 1) / (N * L * M);
         chunks = std::max(chunks, std::min(want, (Lq + 63) / 64));
         const int chunk_q = (Lq + chunks - 1) / chunks;
-        const size_t slds = (size_t)kLvlQ * kD * 4 + ((size_t)chunk_q * P * 4 + 8) * 8 + (size_t)2 * kLvlRows * 4;
-        static bool lds_ok = false;
-        if (!lds_ok) {
-            // (the kernel also has a few bytes of static LDS: leave room for them)
-            const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_scatter_d32_lvl<IO>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-            if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_backward: hipFuncSetAttribute: %s", hipGetErrorString(ae));
-            lds_ok = true;
-        }
-        const int64_t sgrid = (int64_t)N * chunks * L * M;
-        SEMIDETR_REQUIRE(sgrid < INT32_MAX && slds <= 159 * 1024, SEMIDETR_E_TOOLARGE, "msda_backward: level scatter launch too large");
-        hipLaunchKernelGGL((msda_bwd_scatter_d32_lvl<IO>), dim3((unsigned)sgrid), dim3(kLvlThreads), slds, st, grad_out,
-                           spatial_shapes, level_start, io, S, M, L, Lq, P, chunks, chunk_q, grad_value);
-        g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_lvl";
-        return semidetr::launch_status("msda_bwd_scatter_d32_lvl");
+        const int gt = (Lq + 31) / 32;                                   // gather: 32 query rows per 256-thread block
+        const int64_t gblocks = (int64_t)N * gt * M, sblocks = (int64_t)N * chunks * L * M;
+        const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
+        const size_t slds = std::max((size_t)kLvlQ * kD * 4 + ((size_t)chunk_q * P * 4 + 8) * 8 + (size_t)2 * kLvlRows * 4,
+                                     2 * half_f4 * 16);
+        const int64_t grid = sblocks + (gblocks + 1) / 2;
+        SEMIDETR_REQUIRE(grid < INT32_MAX && slds <= 159 * 1024, SEMIDETR_E_TOOLARGE, "msda_backward: merged launch too large");
+#define LAUNCH_MERGED(KLP_)                                                                                          \
+        do {                                                                                                             \
+            static bool lds_ok = false; /* dynamic LDS above 64 KB has to be allowed once per kernel (static LDS too) */ \
+            if (!lds_ok) {                                                                                               \
+                const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_lvl_merged<IO, KLP_>), \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);      \
+                if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_backward: hipFuncSetAttribute: %s", hipGetErrorString(ae)); \
+                lds_ok = true;                                                                                           \
+            }                                                                                                            \
+            hipLaunchKernelGGL((msda_bwd_lvl_merged<IO, KLP_>), dim3((unsigned)grid), dim3(kLvlThreads), slds, st, grad_out, \
+                               value, spatial_shapes, level_start, io, S, M, L, Lq, P, chunks, chunk_q, (int)sblocks, gt, \
+                               (int)gblocks, grad_value);                                                              \
+        } while (0)
+        if (L * P == 16) LAUNCH_MERGED(16);
+        else LAUNCH_MERGED(0);
+#undef LAUNCH_MERGED
+        g_last_kernels = "fillBufferAligned+msda_bwd_lvl_merged";
+        return semidetr::launch_status("msda_bwd_lvl_merged");
     }
     const bool fused = g_bwd_variant != 808 && g_bwd_variant != 832;
     if (fused) {

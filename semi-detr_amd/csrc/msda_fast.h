@@ -153,9 +153,13 @@ constexpr int kHeadRun = 64;
 struct Tile {
     int n, q0, m;
 };
+__device__ __forceinline__ Tile tile_of(int b, int M, int tiles_per_image, int rows_per_block);
 __device__ __forceinline__ Tile tile_of_block(int M, int tiles_per_image, int rows_per_block)
 {
-    const int b = blockIdx.x;
+    return tile_of((int)blockIdx.x, M, tiles_per_image, rows_per_block);
+}
+__device__ __forceinline__ Tile tile_of(int b, int M, int tiles_per_image, int rows_per_block)
+{
     Tile t;
     const int r = b / M;
     t.m = (b % M + r / kHeadRun) % M;
@@ -411,23 +415,26 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
 // compiler can keep 16 corner loads in flight like the forward does) and go to global memory straight from there.
 // PATCH = PH * 100 + PW: the 32 queries of a workgroup are a patch of one level (num_query == spatial_size), as in
 // the forward; 0: 32 consecutive queries.
-template <typename IO = LocAttnIO, int KLP = 0, int PATCH = 0>
-__global__ __launch_bounds__(256) void msda_bwd_gather_d32(
-    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
+// The body is a device function of (virtual block, thread in 0..255, LDS base, active) so that the merged backward
+// launch (msda_bwd_lvl_merged) can run two of these per 512-thread workgroup next to its scatter workgroups; an
+// inactive half (odd block count) walks through the same barriers without touching global memory.
+template <typename IO, int KLP, int PATCH>
+__device__ __forceinline__ void gather_body(
+    const int bid, const int tid, float4 *smem, const bool active, const float *__restrict__ gout,
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
 {
     constexpr int RPB = 32;
-    extern __shared__ float4 smem[];
     const int LP = L * P, LPP = LP + 1;
     int4 *rec_off = reinterpret_cast<int4 *>(smem);
     float4 *rec_p = smem + RPB * LPP;   // {lw, lh, a, level} ; overwritten with {g_attn, g_x, g_y, -}
     float *lev_w = reinterpret_cast<float *>(smem + 2 * RPB * LPP), *lev_h = lev_w + kMaxLevels;
 
-    const Tile t = tile_of_block(M, tiles_per_image, RPB);
+    const Tile t = tile_of(bid, M, tiles_per_image, RPB);
     const int rs = M * kD;
-    if (threadIdx.x < L) {
-        lev_h[threadIdx.x] = (float)shapes[2 * threadIdx.x];
-        lev_w[threadIdx.x] = (float)shapes[2 * threadIdx.x + 1];
+    if (tid < L) {
+        lev_h[tid] = (float)shapes[2 * tid];
+        lev_w[tid] = (float)shapes[2 * tid + 1];
     }
     constexpr int PH = PATCH / 100, PW = PATCH % 100;
     static_assert(PATCH == 0 || PH * PW == RPB, "a patch holds exactly the workgroup's rows");
@@ -439,8 +446,8 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
         if (pt.Hq == 0) return;
         __syncthreads();      // previous patch done with the LDS records
     }
-    auto query_of = [&](int rr_) { return PATCH ? patch_query<PW ? PW : 1>(pt, rr_) : (t.q0 + rr_ < Lq ? t.q0 + rr_ : -1); };
-    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+    auto query_of = [&](int rr_) { return !active ? -1 : (PATCH ? patch_query<PW ? PW : 1>(pt, rr_) : (t.q0 + rr_ < Lq ? t.q0 + rr_ : -1)); };
+    for (int s = tid; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
         const int q = query_of(r);
         unsigned off[4] = {kOob, kOob, kOob, kOob};
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
     }
     __syncthreads();
 
-    const int r = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int r = tid >> 3, j = tid & 7;
     const int q = query_of(r);
     const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
     const unsigned lane_b = (unsigned)(t.m * kD + 4 * j) * 4u;
@@ -566,7 +573,7 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
         }
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
+    for (int s = tid; s < RPB * LP; s += 256) {
         const int rr = s / LP, k = s - rr * LP;
         const int qq = query_of(rr);
         if (qq < 0) continue;
@@ -576,6 +583,16 @@ __global__ __launch_bounds__(256) void msda_bwd_gather_d32(
     }
     if (!PATCH) return;
     }
+}
+
+template <typename IO = LocAttnIO, int KLP = 0, int PATCH = 0>
+__global__ __launch_bounds__(256) void msda_bwd_gather_d32(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
+{
+    extern __shared__ float4 smem[];
+    gather_body<IO, KLP, PATCH>((int)blockIdx.x, (int)threadIdx.x, smem, true, gout, value, shapes, starts, io, S, M, L, Lq, P,
+                                tiles_per_image);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -994,12 +1011,12 @@ constexpr int kLvlQ = 256;               // queries per workgroup
 constexpr int kLvlRows = 4352;           // largest level that is bucketed (counters: 2 x 17 KB of LDS)
 
 template <typename IO>
-__global__ __launch_bounds__(kLvlThreads) void msda_bwd_scatter_d32_lvl(
-    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts, const IO io,
-    int S, int M, int L, int Lq, int P, int chunks, int chunk_q, float *__restrict__ gvalue)
+__device__ __forceinline__ void lvl_scatter_body(
+    int b, float4 *smem, const float *__restrict__ gout, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int chunks, int chunk_q,
+    float *__restrict__ gvalue)
 {
     constexpr int NT = kLvlThreads, kStreams = NT / 16;
-    extern __shared__ float4 smem[];
     // layout: gtile [kLvlQ * 32 floats] | entries [emax float2] | cnt [kLvlRows] | start [kLvlRows]
     float *gtile = reinterpret_cast<float *>(smem);
     float2 *entries = reinterpret_cast<float2 *>(gtile + kLvlQ * kD);
@@ -1012,7 +1029,6 @@ __global__ __launch_bounds__(kLvlThreads) void msda_bwd_scatter_d32_lvl(
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hw = tid >> 5, c = tid & 31;
     // block -> (chunk, level, head, image): heads fastest (XCD = head), levels next so that the four levels of a chunk
     // (different amounts of work) are spread over the launch
-    int b = blockIdx.x;
     const int m = b % M; b /= M;
     const int l = b % L; b /= L;
     const int ch = b % chunks, n = b / chunks;
@@ -1194,4 +1210,36 @@ __global__ __launch_bounds__(kLvlThreads) void msda_bwd_scatter_d32_lvl(
         }
         if (cur >= 0) flush(cur);
     }
+}
+
+template <typename IO>
+__global__ __launch_bounds__(kLvlThreads) void msda_bwd_scatter_d32_lvl(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts, const IO io,
+    int S, int M, int L, int Lq, int P, int chunks, int chunk_q, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    lvl_scatter_body<IO>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, Lq, P, chunks, chunk_q, gvalue);
+}
+
+// ONE launch for both halves of the backward of an arbitrary query set: workgroups [0, scatter_blocks) run the
+// level-aggregated scatter above, the rest run the gather (two 256-thread gather blocks per 512-thread workgroup).  The
+// halves write disjoint outputs (grad_value vs grad_sampling_loc / grad_attn_weight) and stress different units (LDS +
+// atomics vs the vector-memory path), so they overlap instead of queueing -- without the cross-stream events that made
+// the side-stream experiment lose.  Scatter workgroups come first: they are the long pole.
+template <typename IO, int KLP>
+__global__ __launch_bounds__(kLvlThreads) void msda_bwd_lvl_merged(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int chunks, int chunk_q,
+    int scatter_blocks, int gather_tiles, int gather_blocks, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    if ((int)blockIdx.x < scatter_blocks) {
+        lvl_scatter_body<IO>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, Lq, P, chunks, chunk_q, gvalue);
+        return;
+    }
+    const int half = (int)threadIdx.x >> 8;
+    const int vb = 2 * ((int)blockIdx.x - scatter_blocks) + half;
+    const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;       // LDS of one gather block, in float4
+    gather_body<IO, KLP, 0>(vb, (int)threadIdx.x & 255, smem + half * half_f4, vb < gather_blocks, gout, value, shapes,
+                            starts, io, S, M, L, Lq, P, gather_tiles);
 }

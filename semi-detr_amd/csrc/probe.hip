@@ -8,42 +8,53 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// every thread moves kPer consecutive-by-stride float4s; loads first, then stores (kPer independent requests in flight)
-constexpr int kPer = 8;
-template <bool NT>
-__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
-                                                          int64_t n4)
+// Shape found with tools/stream_probe.hip on this pool's boxes (1 GiB arrays): one contiguous 16 KB region per
+// workgroup, four float4 per thread, loads before stores -> 5.8 TB/s copy (read + write); a grid-stride kernel with
+// 2 K - 16 K workgroups reaches 4.4 - 5.0, hipMemcpyDtoD 4.9, tensor.copy_ 5.1.  Read-only the same shape streams
+// 6.2 - 6.5 TB/s, write-only 6.0.
+constexpr int kPer = 4;
+template <int MODE>      // 0 copy, 1 copy with nontemporal accesses, 2 read only (sum folded into a never-true store)
+__global__ __launch_bounds__(256) void stream_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int64_t n4)
 {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t base = (int64_t)blockIdx.x * 256 + threadIdx.x; base < n4; base += stride * kPer) {
-        f32x4 v[kPer];
+    const int64_t base = (int64_t)blockIdx.x * (256 * kPer) + threadIdx.x;
+    f32x4 v[kPer];
 #pragma unroll
-        for (int i = 0; i < kPer; ++i)
-            if (base + i * stride < n4) v[i] = NT ? __builtin_nontemporal_load(src + base + i * stride) : src[base + i * stride];
+    for (int i = 0; i < kPer; ++i) {
+        const int64_t k = base + i * 256;
+        if (k < n4) v[i] = MODE == 1 ? __builtin_nontemporal_load(src + k) : src[k];
+        else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (MODE == 2) {
+        f32x4 a = v[0];
 #pragma unroll
-        for (int i = 0; i < kPer; ++i)
-            if (base + i * stride < n4) {
-                if (NT) __builtin_nontemporal_store(v[i], dst + base + i * stride);
-                else dst[base + i * stride] = v[i];
-            }
+        for (int i = 1; i < kPer; ++i) a += v[i];
+        if (a.x + a.y + a.z + a.w == 1.2345e33f) dst[0] = a;       // keeps the loads alive, practically never taken
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int64_t k = base + i * 256;
+        if (k < n4) {
+            if (MODE == 1) __builtin_nontemporal_store(v[i], dst + k);
+            else dst[k] = v[i];
+        }
     }
 }
 
 }  // namespace
 
-extern "C" int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel, int nontemporal)
+extern "C" int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel, int mode)
 {
     SEMIDETR_REQUIRE(dst && src && numel > 0 && numel % 4 == 0, SEMIDETR_E_BADARG,
                      "stream_copy: need non-null pointers and a positive multiple of 4 elements");
     SEMIDETR_REQUIRE((((uintptr_t)dst | (uintptr_t)src) & 15) == 0, SEMIDETR_E_BADARG, "stream_copy: 16-byte alignment");
     const int64_t n4 = numel / 4;
-    const int64_t want = (n4 + 256 * kPer - 1) / (256 * kPer);
-    const unsigned grid = (unsigned)(want < 256 * 32 ? (want > 0 ? want : 1) : 256 * 32);
-    if (nontemporal)
-        hipLaunchKernelGGL(stream_copy_kernel<true>, dim3(grid), dim3(256), 0, semidetr::as_stream(stream),
-                           reinterpret_cast<const f32x4 *>(src), reinterpret_cast<f32x4 *>(dst), n4);
-    else
-        hipLaunchKernelGGL(stream_copy_kernel<false>, dim3(grid), dim3(256), 0, semidetr::as_stream(stream),
-                           reinterpret_cast<const f32x4 *>(src), reinterpret_cast<f32x4 *>(dst), n4);
+    const int64_t grid = (n4 + 256 * kPer - 1) / (256 * kPer);
+    SEMIDETR_REQUIRE(grid < INT32_MAX && mode >= 0 && mode <= 2, SEMIDETR_E_BADARG, "stream_copy: bad size / mode");
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
+    if (mode == 0) hipLaunchKernelGGL(stream_kernel<0>, dim3((unsigned)grid), dim3(256), 0, semidetr::as_stream(stream), s4, d4, n4);
+    else if (mode == 1) hipLaunchKernelGGL(stream_kernel<1>, dim3((unsigned)grid), dim3(256), 0, semidetr::as_stream(stream), s4, d4, n4);
+    else hipLaunchKernelGGL(stream_kernel<2>, dim3((unsigned)grid), dim3(256), 0, semidetr::as_stream(stream), s4, d4, n4);
     return semidetr::launch_status("stream_copy_kernel");
 }
