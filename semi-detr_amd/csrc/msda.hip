@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -449,9 +450,12 @@ int launch_strips_backward(hipStream_t st, size_t fill, const float *grad_out, c
         // fill, then ONE launch: level-aggregated scatter workgroups + gather workgroups side by side
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
         if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-        // chunks of <= kLvlQ queries; small launches are cut finer so that about one workgroup per CU exists
+        // chunks of <= kLvlQ queries; small launches are cut finer so that at least ~128 scatter workgroups exist.  Measured
+        // at the micro-benchmark shape (N=2, Lq=300: 64 (image, head, level) triples): 1 chunk 42.1 us, 2 chunks 36.1 us,
+        // 4 chunks 40.1 us, 8 chunks 38.7 us -- bigger chunks aggregate more, a single one leaves the chip idle.
         int chunks = (Lq + kLvlQ - 1) / kLvlQ;
-        const int want = (256 + N * L * M - 1) / (N * L * M);
+        static const int target_wgs = getenv("SEMIDETR_LVL_WGS") ? atoi(getenv("SEMIDETR_LVL_WGS")) : 128;   // tuning aid
+        const int want = (target_wgs + N * L * M - 1) / (N * L * M);
         chunks = std::max(chunks, std::min(want, (Lq + 63) / 64));
         const int chunk_q = (Lq + chunks - 1) / chunks;
         const int gt = (Lq + 31) / 32;                                   // gather: 32 query rows per 256-thread block
