@@ -532,11 +532,41 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || (g_bwd_variant >= 64 && g_bwd_variant <= 74)) {
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74))) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
         if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+        if (g_bwd_variant == 68 && L * P == 16 && P == kPT) {
+            // Experiment (variant 68): ONE launch, windowed-scatter workgroups interleaved with pairs of gather blocks
+            // (msda_bwd_enc_merged).  Measured at bs 4: 1771 us against 879 us for the two launches -- every workgroup of
+            // the launch carries the scatter's 77 KB of LDS, so a CU holds two workgroups in any mix and the gather, which
+            // needs 16-24 waves per CU to stream, is left with 8.  (The same trick WINS for arbitrary query sets, where
+            // the scatter's LDS is small enough for the halves to share CUs at full occupancy: msda_bwd_lvl_merged.)
+            const int tiles_bound = (S + 255) / 256 * 5 / 4 + 4 * L;
+            const int gbound = (S + 31) / 32 * 5 / 4 + 4 * L;
+            const int64_t sblocks = (int64_t)N * tiles_bound * M, gblocks = (int64_t)N * gbound * M;
+            const int64_t gwgs = (gblocks + 1) / 2, total = sblocks + gwgs;
+            const int period = (int)std::max<int64_t>(2, total / sblocks);         // every period-th workgroup scatters
+            // all scatter indices 0, period, 2*period, ... must fall inside the grid
+            const int64_t grid = std::max(total, (sblocks - 1) * period + 1);
+            SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+            const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
+            const size_t mlds = std::max(win_lds_bytes<16, 16, 32, 32>(), 2 * half_f4 * 16);
+            static bool lds_ok = false;
+            if (!lds_ok) {
+                const hipError_t ae = hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&msda_bwd_enc_merged<IO, 16, 16, 16, 32, 32>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_backward: hipFuncSetAttribute: %s", hipGetErrorString(ae));
+                lds_ok = true;
+            }
+            hipLaunchKernelGGL((msda_bwd_enc_merged<IO, 16, 16, 16, 32, 32>), dim3((unsigned)grid), dim3(kWinThreads), mlds, st,
+                               grad_out, value, spatial_shapes, level_start, io, S, M, L, P, tiles_bound, (int)sblocks, gbound,
+                               (int)gblocks, period, grad_value);
+            g_last_kernels = "fillBufferAligned+msda_bwd_enc_merged";
+            return semidetr::launch_status("msda_bwd_enc_merged");
+        }
         {   // gather half: the two small gradients, streams like the forward
             const int gt = (Lq + 31) / 32;
             const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
@@ -590,12 +620,26 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         const int tiles_bound = (S + patch - 1) / patch * 5 / 4 + 4 * L;
         const int64_t grid = (int64_t)N * tiles_bound * M;
         SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
-        if (big)
+        const size_t wlds = big ? win_lds_bytes<16, 16, 32, 32>() : win_lds_bytes<8, 16, 24, 32>();
+#define ALLOW_LDS(KERNEL)                                                                                            \
+        do {                                                                                                             \
+            static bool lds_ok = false;                                                                                  \
+            if (!lds_ok) {                                                                                               \
+                const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL),                       \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);      \
+                if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_backward: hipFuncSetAttribute: %s", hipGetErrorString(ae)); \
+                lds_ok = true;                                                                                           \
+            }                                                                                                            \
+        } while (0)
+        if (big) {
+            ALLOW_LDS((msda_bwd_scatter_d32_win<IO, 16, 16, 32, 32>));
             hipLaunchKernelGGL((msda_bwd_scatter_d32_win<IO, 16, 16, 32, 32>), dim3((unsigned)grid), dim3(kWinThreads),
-                               0, st, grad_out, spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
-        else
+                               wlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
+        } else {
+            ALLOW_LDS((msda_bwd_scatter_d32_win<IO, 8, 16, 24, 32>));
             hipLaunchKernelGGL((msda_bwd_scatter_d32_win<IO, 8, 16, 24, 32>), dim3((unsigned)grid), dim3(kWinThreads),
-                               0, st, grad_out, spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
+                               wlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
+        }
         g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_win";
         return semidetr::launch_status("msda_bwd_scatter_d32_win");
     }

@@ -418,7 +418,10 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
 // The body is a device function of (virtual block, thread in 0..255, LDS base, active) so that the merged backward
 // launch (msda_bwd_lvl_merged) can run two of these per 512-thread workgroup next to its scatter workgroups; an
 // inactive half (odd block count) walks through the same barriers without touching global memory.
-template <typename IO, int KLP, int PATCH>
+// PAIR: two gather blocks share one 512-thread workgroup (merged launches): __syncthreads() is workgroup-wide, so both
+// halves must take the same barriers -- a half that has run out of patches keeps walking, inactive, until the other is
+// done too (decided by __syncthreads_or).
+template <typename IO, int KLP, int PATCH, bool PAIR = false>
 __device__ __forceinline__ void gather_body(
     const int bid, const int tid, float4 *smem, const bool active, const float *__restrict__ gout,
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
@@ -443,10 +446,15 @@ __device__ __forceinline__ void gather_body(
     for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
     if (PATCH) {
         pt = find_patch<PH ? PH : 1, PW ? PW : 1>(tile, shapes, starts, L);
-        if (pt.Hq == 0) return;
+        if (PAIR) {
+            if (!__syncthreads_or(active && pt.Hq != 0)) return;     // both halves are out of patches
+        } else if (pt.Hq == 0) {
+            return;
+        }
         __syncthreads();      // previous patch done with the LDS records
     }
-    auto query_of = [&](int rr_) { return !active ? -1 : (PATCH ? patch_query<PW ? PW : 1>(pt, rr_) : (t.q0 + rr_ < Lq ? t.q0 + rr_ : -1)); };
+    const bool live = active && (!PATCH || pt.Hq != 0);
+    auto query_of = [&](int rr_) { return !live ? -1 : (PATCH ? patch_query<PW ? PW : 1>(pt, rr_) : (t.q0 + rr_ < Lq ? t.q0 + rr_ : -1)); };
     for (int s = tid; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
         const int q = query_of(r);
@@ -622,26 +630,34 @@ constexpr int kScatterHeadRun = 16;                     // head rotation, see ti
 
 // TH x TW = query patch (pixels), WH x WW = value-row window per sampling level (both compile time).
 // Every thread owns SPT = TH*TW*4 / 512 (query, point) samples of the patch.
+// LDS of one windowed-scatter workgroup, carved from the dynamic allocation (so that the merged encoder backward launch
+// can give the same bytes to a pair of gather blocks instead): sizes in bytes
+template <int TH, int TW, int WH, int WW>
+constexpr size_t win_lds_bytes()
+{
+    return (size_t)(TH * TW * kPT * 4 + 8) * 8 + (size_t)TH * TW * kD * 4 + (size_t)3 * WH * WW * 4 + 8 * 4 + (kWinThreads / 64) * 4 + 16;
+}
+
 template <typename IO, int TH, int TW, int WH, int WW>
-__global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
-    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
-    const IO io, int S, int M, int L, int tiles_bound, float *__restrict__ gvalue)
+__device__ __forceinline__ void win_scatter_body(
+    const int b, float4 *smem, const float *__restrict__ gout, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int tiles_bound, float *__restrict__ gvalue)
 {
     constexpr int kTQ = TH * TW, kWR = WH * WW, kNE = kTQ * kPT * 4, SPT = kTQ * kPT / kWinThreads;
     static_assert(SPT * kWinThreads == kTQ * kPT && SPT >= 1, "whole samples per thread");
     static_assert(kWR <= 2 * kWinThreads, "scan assigns two counters per thread");
     static_assert(kTQ <= 256 && kWR <= (1 << 14), "entry packing: 8 bits query, row above");
-    __shared__ float2 entries[kNE + 8];          // front: bucketed {weight, last << 30 | window row << 8 | query}
-                                                 //        (+8: batch reads may run past a share's end, unused);
-                                                 // back : misses {weight, query << 24 | pixel index}
-    __shared__ float gtile[kTQ * kD];            // grad_out rows of the patch
-    __shared__ int cnt[kWR], start[kWR], rowoff[kWR];   // per window row: count, first entry, element offset
-    __shared__ int stats2[2][4], wsum[kWinThreads / 64];   // stats double-buffered by level parity: a fast
-                                                           // wavefront may start level l+1 while others still read l's
+    float2 *entries = reinterpret_cast<float2 *>(smem);   // [kNE + 8] front: bucketed {weight, last << 30 | window row << 8 | query}
+                                                          //        (+8: batch reads may run past a share's end, unused);
+                                                          // back : misses {weight, query << 24 | pixel index}
+    float *gtile = reinterpret_cast<float *>(entries + kNE + 8);          // [kTQ * kD] grad_out rows of the patch
+    int *cnt = reinterpret_cast<int *>(gtile + kTQ * kD);                // per window row: count,
+    int *start = cnt + kWR, *rowoff = start + kWR;                       //   first entry, element offset
+    int (*stats2)[4] = reinterpret_cast<int (*)[4]>(rowoff + kWR);       // [2][4] stats double-buffered by level parity: a fast
+    int *wsum = reinterpret_cast<int *>(stats2 + 2);                     //   wavefront may start level l+1 while others still read l's
 
     constexpr int P = kPT;
     const int Lq = S, LP = L * P, rs = M * kD;
-    const int b = blockIdx.x;
     const int m = (b % M + (b / M) / kScatterHeadRun) % M;
     const int slot = (b / M) % tiles_bound, n = (b / M) / tiles_bound;
     const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
@@ -856,6 +872,43 @@ __global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
             }
         }
     }
+}
+
+template <typename IO, int TH, int TW, int WH, int WW>
+__global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_scatter_d32_win(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int tiles_bound, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    win_scatter_body<IO, TH, TW, WH, WW>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, tiles_bound, gvalue);
+}
+
+// ONE launch for both halves of the encoder backward: every `period`-th workgroup runs the windowed scatter, the others
+// run two 4 x 8-patch gather blocks each.  The halves write disjoint outputs and lean on different units (LDS / issue /
+// atomics vs the vector-memory path); in one launch they share the CUs from the first microsecond instead of queueing,
+// and without the cross-stream events that made two-stream overlap lose.  All workgroups carry the scatter's LDS size,
+// so any mix of two fits a CU.
+template <typename IO, int KLP, int TH, int TW, int WH, int WW>
+__global__ __launch_bounds__(kWinThreads, 4) void msda_bwd_enc_merged(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int P, int tiles_bound, int scatter_blocks,
+    int gather_bound, int gather_blocks, int period, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    const int b = (int)blockIdx.x;
+    // blocks 0, period, 2*period, ... (while scatter blocks remain) are scatter blocks
+    const int ns_before = min((b + period - 1) / period, scatter_blocks);      // scatter blocks with index < b
+    const bool is_scatter = (b % period == 0) && (b / period < scatter_blocks);
+    if (is_scatter) {
+        win_scatter_body<IO, TH, TW, WH, WW>(b / period, smem, gout, shapes, starts, io, S, M, L, tiles_bound, gvalue);
+        return;
+    }
+    const int gi = b - ns_before;                                              // index among the gather workgroups
+    const int half = (int)threadIdx.x >> 8;
+    const int vb = 2 * gi + half;
+    const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
+    gather_body<IO, KLP, 408, true>(vb, (int)threadIdx.x & 255, smem + half * half_f4, vb < gather_blocks, gout, value,
+                                    shapes, starts, io, S, M, L, S, P, gather_bound);
 }
 
 // ---------------------------------------------------------------------------------------------
