@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 
 #include "msda_fast.h"   // IO policies + the D == 32 fp32 kernels
 #include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
+#include "msda_region.h" // region-owned windowed scatter for encoder self-attention
 
 int g_fwd_variant = 0, g_bwd_variant = 0;
 
@@ -532,7 +533,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74))) {
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || g_bwd_variant == 690)) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
@@ -583,6 +584,36 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                 hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
                                    grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
+        }
+        if ((g_bwd_variant == 0 || g_bwd_variant == 69 || g_bwd_variant == 690) && P == kPT && S < (1 << 23)) {
+            // region-owned windowed scatter (msda_region.h): one workgroup per tile of the finest level, all query levels.
+            // DEFAULT since round 2.  Measured at the 800x1333 encoder shape (backward incl. fill + gather): bs 4 886 us
+            // (windowed kernel, variant 65) -> 867 us (16 x 16 regions, 1024 threads, 690) -> 823 us (8 x 16 regions, 512
+            // threads, two workgroups per CU); bs 1 248 -> 226 -> 216 us; row atomics 590 MB -> 358 MB (16 x 16).
+            const bool small = g_bwd_variant != 690;              // 8 x 16 regions, 512 threads, two workgroups per CU
+            const int rpx = small ? 128 : 256;
+            const int rbound = (S + rpx - 1) / rpx * 5 / 4 + 4 * L;
+            const int64_t rgrid = (int64_t)N * rbound * M;
+            SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+#define LAUNCH_REG(NT_, Q_, RH_, RW_, WH_, WW_)                                                                      \
+            do {                                                                                                         \
+                static bool lds_ok = false;                                                                              \
+                auto kern = &msda_bwd_scatter_d32_reg<IO, NT_, Q_, RH_, RW_, WH_, WW_>;                                   \
+                if (!lds_ok) {                                                                                           \
+                    const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);  \
+                    if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_backward: hipFuncSetAttribute: %s", hipGetErrorString(ae)); \
+                    lds_ok = true;                                                                                       \
+                }                                                                                                        \
+                const size_t rlds = reg_lds_bytes<NT_, Q_, WH_, WW_>();                                                  \
+                hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(NT_), rlds, st, grad_out, spatial_shapes, level_start, \
+                                   io, S, M, L, rbound, grad_value);                                                    \
+            } while (0)
+            if (small) LAUNCH_REG(512, 208, 8, 16, 24, 32);
+            else LAUNCH_REG(1024, 384, 16, 16, 32, 32);
+#undef LAUNCH_REG
+            g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg";
+            return semidetr::launch_status("msda_bwd_scatter_d32_reg");
         }
         // grad_value: destination-owned tiles (msda_dest.h) unless a windowed variant is forced (64..67) or the pyramid
         // has more levels than the kernel's LDS tables hold

@@ -1,0 +1,296 @@
+// grad_value for encoder self-attention, REGION-owned windowed scatter (fp32, D == 32, num_point == 4).  Included by
+// msda.hip after msda_fast.h; the successor of msda_bwd_scatter_d32_win.
+//
+// The windowed kernel takes a 16 x 16 patch of queries of ONE level per workgroup.  Its row atomics (4.7 M per bs-4
+// launch = 454 us of the atomic unit, the kernel's binding resource at 552 us) have two avoidable parts:
+//   * every query level flushes its own copy of the rows it shares with the other levels' queries of the same image
+//     region (a level-1 patch covers the area of four level-0 patches and flushes the same level-0 .. level-3 rows again);
+//   * the footprint of a coarse-level patch on the fine levels is larger than the 32 x 32 window, so 19 % of all atomics
+//     are window misses scattered one by one.
+// Here a workgroup owns a REGION of the image -- a 16 x 16 tile of the finest level -- and takes the queries of ALL levels
+// whose pixel centres lie in it (256 + 64 + 16 + 4 for a halving pyramid, <= kRegQ).  Their samples on level l all fall
+// around the same spot, so ONE window per sampling level serves every query level: the rows are flushed once per region
+// instead of once per (query level, patch), and coarse-level queries no longer miss.  Everything else is the windowed
+// kernel's machinery: grad_out of the region's queries staged in LDS, (sample, corner) pairs bucketed by window row with
+// integer LDS atomics (count -> scan -> fill), 64 streams of 16 lanes walking equal shares of the row-sorted entries with
+// the row sum in registers, one full-line atomic per row run, misses scattered one by one (any sampling pattern is
+// correct).
+// A region with more than kRegQ queries (pyramids whose coarse levels are not much smaller) is processed in several
+// passes over slices of its query list.
+#pragma once
+
+// NT threads; kRegQ queries per pass; region = RTH x RTW pixels of the finest level; WH x WW window per sampling level.
+// Two configurations are instantiated: <1024, 384, 16, 16, 32, 32> (one workgroup per CU) and <512, 208, 8, 16, 24, 32>
+// (two per CU: the phases of one hide the barriers of the other).
+template <int NT, int kRegQ, int WH, int WW>
+constexpr size_t reg_lds_bytes()
+{
+    return (size_t)(kRegQ * kPT * 4 + 8) * 8 + (size_t)kRegQ * kD * 4 + (size_t)3 * WH * WW * 4 + (size_t)kRegQ * 4 +
+           8 * 4 + (NT / 64) * 4 + 4 * kMaxLevels * 4 + 64;
+}
+
+template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW>
+__global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
+{
+    constexpr int kWR = WH * WW, kNE = kRegQ * kPT * 4, SPT = (kRegQ * kPT + NT - 1) / NT, KC = (kWR + NT - 1) / NT;
+    static_assert(kRegQ <= 512 && kWR <= (1 << 14), "entry packing: 9 bits query slot, window row above");
+    extern __shared__ float4 smem[];
+    float2 *entries = reinterpret_cast<float2 *>(smem);   // [kNE + 8] front: bucketed {weight, last << 30 | window row << 9 | slot};
+                                                          // back: misses {weight, slot << 23 | pixel index}
+    float *gtile = reinterpret_cast<float *>(entries + kNE + 8);          // [kRegQ * kD] grad_out rows of the region's queries
+    int *cnt = reinterpret_cast<int *>(gtile + kRegQ * kD);
+    int *start = cnt + kWR, *rowoff = start + kWR;
+    int *qlist = rowoff + kWR;                                            // [kRegQ] query index of every slot
+    int (*stats2)[4] = reinterpret_cast<int (*)[4]>(qlist + kRegQ);
+    int *wsum = reinterpret_cast<int *>(stats2 + 2);                      // [NT / 64]
+    int *lv = wsum + NT / 64;                                             // [4][kMaxLevels]: y_lo, x_lo, width, slot offset
+
+    constexpr int P = kPT;
+    const int Lq = S, LP = L * P, rs = M * kD;
+    const int b = blockIdx.x;
+    const int m = (b % M + (b / M) / kScatterHeadRun) % M;
+    const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
+    const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
+
+    // the finest level (most pixels) carries the region grid
+    int lb = 0, Hb = (int)shapes[0], Wb = (int)shapes[1];
+    for (int l = 1; l < L; ++l) {
+        const int h = (int)shapes[2 * l], w = (int)shapes[2 * l + 1];
+        if (h * w > Hb * Wb) { lb = l; Hb = h; Wb = w; }
+    }
+    (void)lb;
+    const int nry = (Hb + RTH - 1) / RTH, nrx = (Wb + RTW - 1) / RTW;
+
+    for (int reg = slot0; reg < nry * nrx; reg += regions_bound) {
+        const int y0b = (reg / nrx) * RTH, x0b = (reg % nrx) * RTW;
+        const int y1b = min(y0b + RTH, Hb), x1b = min(x0b + RTW, Wb);
+        __syncthreads();                      // previous region fully done before its LDS state is reused
+        // ---- the region's queries: on level lq the pixels whose centre maps into [y0b, y1b) x [x0b, x1b) of the finest
+        //      level -- by(qy) = ((2 qy + 1) Hb) / (2 Hq) is monotone, so they form an exact rectangle
+        if (tid < L) {
+            const int Hq = (int)shapes[2 * tid], Wq = (int)shapes[2 * tid + 1];
+            auto first = [](int bound, int nq_, int nb) {      // smallest q with ((2q+1) nb) / (2 nq_) >= bound
+                const long long a = 2ll * nq_ * bound;
+                const int cc = (int)((a + nb - 1) / nb);       // 2q + 1 >= ceil(a / nb)
+                return min(nq_, cc >> 1);
+            };
+            const int ylo = first(y0b, Hq, Hb), yhi = y1b >= Hb ? Hq : first(y1b, Hq, Hb);
+            const int xlo = first(x0b, Wq, Wb), xhi = x1b >= Wb ? Wq : first(x1b, Wq, Wb);
+            lv[0 * kMaxLevels + tid] = ylo;
+            lv[1 * kMaxLevels + tid] = xlo;
+            lv[2 * kMaxLevels + tid] = max(xhi - xlo, 0);
+            lv[3 * kMaxLevels + tid] = max(yhi - ylo, 0) * max(xhi - xlo, 0);      // count, turned into an offset below
+        }
+        __syncthreads();
+        int nq_total = 0;
+        for (int l = 0; l < L; ++l) nq_total += lv[3 * kMaxLevels + l];
+        // region centre in normalised coordinates (pixel centres are (i + 0.5) / size)
+        const float pcy = (y0b + 0.5f * RTH) / (float)Hb, pcx = (x0b + 0.5f * RTW) / (float)Wb;
+
+        for (int q_base = 0; q_base < nq_total; q_base += kRegQ) {      // one pass unless the region has > kRegQ queries
+            const int nq = min(kRegQ, nq_total - q_base);
+            __syncthreads();
+            for (int i = tid; i < nq; i += NT) {       // slot -> query index
+                int s = q_base + i, lq = 0;
+                while (s >= lv[3 * kMaxLevels + lq]) { s -= lv[3 * kMaxLevels + lq]; ++lq; }
+                const int w = lv[2 * kMaxLevels + lq];
+                qlist[i] = (int)starts[lq] + (lv[0 * kMaxLevels + lq] + s / w) * (int)shapes[2 * lq + 1] + lv[1 * kMaxLevels + lq] + s % w;
+            }
+            __syncthreads();
+            // this thread's samples = (slot i, point p), sample index tid + sp * NT
+            int qs[SPT];
+            int64_t srow[SPT];
+            float sm_max[SPT], sm_inv[SPT];
+#pragma unroll
+            for (int sp = 0; sp < SPT; ++sp) {
+                const int sidx = tid + sp * NT, i = sidx / P, p = sidx - i * P;
+                qs[sp] = i < nq ? qlist[i] : -1;
+                srow[sp] = qs[sp] >= 0 ? ((int64_t)n * Lq + qs[sp]) * M + m : 0;
+                sm_max[sp] = 0.f;
+                sm_inv[sp] = 1.f;
+                if (IO::kSoftmax) {      // fused prologue: softmax statistics of the (query, head) row (quad reductions, P == 4)
+                    float mx = -__builtin_huge_valf();
+                    if (qs[sp] >= 0)
+                        for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow[sp], LP, l * P + p));
+                    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+                    float sum = 0.f;
+                    if (qs[sp] >= 0)
+                        for (int l = 0; l < L; ++l) sum += expf(io.load_w(srow[sp], LP, l * P + p) - mx);
+                    sum += __shfl_xor(sum, 1, 64);
+                    sum += __shfl_xor(sum, 2, 64);
+                    sm_max[sp] = mx;
+                    sm_inv[sp] = 1.f / sum;
+                }
+            }
+            for (int r = hw; r < nq; r += NT / 32)      // stage grad_out of the queries, channels (c, c+16) interleaved
+                gtile[r * kD + (c & 15) * 2 + (c >> 4)] = gout[(((int64_t)n * Lq + qlist[r]) * M + m) * kD + c];
+            for (int l = 0; l < L; ++l) {
+                const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+                // window: where the region centre maps to on this level, minus half the window
+                const int y0 = (int)floorf(pcy * H - 0.5f) - WH / 2 + 1;
+                const int x0 = (int)floorf(pcx * W - 0.5f) - WW / 2 + 1;
+                int *stats = stats2[l & 1];
+                if (tid < 4) stats[tid] = 0;
+                for (int k = tid; k < kWR; k += NT) cnt[k] = 0;
+                // ---- this thread's sample geometry: per corner weight, window row (or -1: miss, -2: no corner)
+                float cw[SPT][4];
+                int wrow[SPT][4], rank[SPT][4], pix[SPT][4];
+#pragma unroll
+                for (int sp = 0; sp < SPT; ++sp) {
+                    const int sidx = tid + sp * NT, p = sidx % P;
+                    int off[4] = {-1, -1, -1, -1};
+                    float lw = 0.f, lh = 0.f, a = 0.f;
+                    int h0 = 0, w0 = 0;
+                    if (qs[sp] >= 0) {
+                        const int k = l * P + p;
+                        float x, y;
+                        io.load_xy(srow[sp], (int64_t)n * Lq + qs[sp], LP, k, l, P, H, W, x, y);
+                        if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+                            a = io.load_w(srow[sp], LP, k);
+                            if (IO::kSoftmax) a = expf(a - sm_max[sp]) * sm_inv[sp];
+                            h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
+                            w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
+                        }
+                    }
+                    const int wy = h0 - y0, wx = w0 - x0;
+                    const bool in_y0 = (unsigned)wy < (unsigned)WH, in_y1 = (unsigned)(wy + 1) < (unsigned)WH;
+                    const bool in_x0 = (unsigned)wx < (unsigned)WW, in_x1 = (unsigned)(wx + 1) < (unsigned)WW;
+                    const int wi = wy * WW + wx;
+                    const float hh = 1.f - lh, hwt = 1.f - lw;
+                    const float cwv[4] = {hh * hwt * a, hh * lw * a, lh * hwt * a, lh * lw * a};
+                    const bool inw[4] = {in_y0 && in_x0, in_y0 && in_x1, in_y1 && in_x0, in_y1 && in_x1};
+                    const int wr[4] = {wi, wi + 1, wi + WW, wi + WW + 1};
+#pragma unroll
+                    for (int cidx = 0; cidx < 4; ++cidx) {
+                        cw[sp][cidx] = cwv[cidx];
+                        wrow[sp][cidx] = off[cidx] < 0 ? -2 : (inw[cidx] ? wr[cidx] : -1);
+                        pix[sp][cidx] = off[cidx] / rs;      // pixel index inside the image (misses only)
+                        rank[sp][cidx] = 0;
+                    }
+                }
+                __syncthreads();                  // counters zeroed, previous level's walk finished
+                // ---- bucket the in-window corners by window row (count), list the others as misses
+#pragma unroll
+                for (int sp = 0; sp < SPT; ++sp) {
+                    const int i = (tid + sp * NT) / P;
+#pragma unroll
+                    for (int cidx = 0; cidx < 4; ++cidx) {
+                        if (wrow[sp][cidx] >= 0) rank[sp][cidx] = atomicAdd(&cnt[wrow[sp][cidx]], 1);
+                        else if (wrow[sp][cidx] == -1)   // pixel index (< 2^23, checked by the launcher) + slot
+                            entries[kNE - 1 - atomicAdd(&stats[1], 1)] = make_float2(
+                                cw[sp][cidx], __int_as_float((int)(((unsigned)i << 23) | (unsigned)pix[sp][cidx])));
+                    }
+                }
+                __syncthreads();
+                // ---- exclusive scan of the kWR counters -> start[]  (thread t owns counters t*KC .. t*KC + KC - 1)
+                {
+                    int cv[KC], v = 0;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        cv[k] = tid * KC + k < kWR ? cnt[tid * KC + k] : 0;
+                        v += cv[k];
+                    }
+                    int incl = v;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int t = __shfl_up(incl, d, 64);
+                        if (lane >= d) incl += t;
+                    }
+                    if (lane == 63) wsum[wv] = incl;
+                    __syncthreads();
+                    int base = 0;
+                    for (int w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+                    int run = base + incl - v;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) {
+                        const int j = tid * KC + k;
+                        if (j < kWR) {
+                            start[j] = run;
+                            // element offset of the window row's pixel inside the image slice (only used for touched rows)
+                            rowoff[j] = (st + (y0 + j / WW) * W + x0 + j % WW) * rs;
+                        }
+                        run += cv[k];
+                    }
+                    if (tid == NT - 1) stats[3] = run;            // total number of bucketed entries
+                }
+                __syncthreads();
+                // ---- fill the buckets; bit 30 marks the last entry of its row
+#pragma unroll
+                for (int sp = 0; sp < SPT; ++sp) {
+                    const int i = (tid + sp * NT) / P;
+#pragma unroll
+                    for (int cidx = 0; cidx < 4; ++cidx) {
+                        const int wr = wrow[sp][cidx];
+                        if (wr >= 0)
+                            entries[start[wr] + rank[sp][cidx]] = make_float2(
+                                cw[sp][cidx], __int_as_float((rank[sp][cidx] == cnt[wr] - 1 ? (1 << 30) : 0) | (wr << 9) | i));
+                    }
+                }
+                __syncthreads();
+                // ---- owner computes: 64 streams of 16 lanes (lane l = channels l and l+16) each walk an equal share of
+                //      the row-sorted entries, running row sum in two registers, one atomic pair per finished row
+                {
+                    constexpr int kStreams = NT / 16;
+                    const int sid = tid >> 4, l16 = tid & 15;
+                    const float2 *gt2 = reinterpret_cast<const float2 *>(gtile);
+                    float *gvs = gvalue + ((int64_t)n * S * M + m) * kD + l16;
+                    const int total = stats[3];
+                    const int lo = (int)((int64_t)total * sid / kStreams);
+                    const int hi = (int)((int64_t)total * (sid + 1) / kStreams);
+                    int cur = -1;           // row of the most recent entry whose sum is still open, or -1
+                    float2 accv = make_float2(0.f, 0.f);
+                    auto flush = [&](int rowi) {
+                        float *pr = gvs + rowoff[rowi];
+                        fp_atomic_add(pr, accv.x);
+                        fp_atomic_add(pr + 16, accv.y);
+                    };
+                    auto step = [&](const float2 &en, const float2 &gq) {
+                        const int pk = __float_as_int(en.y);
+                        accv.x += en.x * gq.x;
+                        accv.y += en.x * gq.y;
+                        cur = (pk >> 9) & 0x1fffff;
+                        if (pk & (1 << 30)) {
+                            flush(cur);
+                            accv = make_float2(0.f, 0.f);
+                            cur = -1;
+                        }
+                    };
+                    int e = lo;
+                    for (; e + 8 <= hi; e += 8) {
+                        float2 en[8], gq[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) en[u] = entries[e + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 511) * 16 + l16];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) step(en[u], gq[u]);
+                    }
+                    if (e < hi) {       // tail of < 8 entries
+                        float2 en[8], gq[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) en[u] = entries[min(e + u, hi - 1)];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 511) * 16 + l16];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (e + u < hi) step(en[u], gq[u]);
+                    }
+                    if (cur >= 0) flush(cur);
+                    // ---- misses: one row update per (sample, corner), as the plain kernel does
+                    const int nmiss = stats[1];
+                    for (int mi = sid; mi < nmiss; mi += kStreams) {
+                        const float2 en = entries[kNE - 1 - mi];
+                        const int pk = __float_as_int(en.y);
+                        const float2 g2 = gt2[((unsigned)pk >> 23) * 16 + l16];
+                        float *pr = gvs + (int64_t)(pk & 0x7fffff) * rs;
+                        fp_atomic_add(pr, en.x * g2.x);
+                        fp_atomic_add(pr + 16, en.x * g2.y);
+                    }
+                }
+            }
+        }
+    }
+}
