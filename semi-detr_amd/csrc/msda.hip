@@ -533,7 +533,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || g_bwd_variant == 690)) {
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 695))) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
@@ -585,13 +585,13 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                                    grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
         }
-        if ((g_bwd_variant == 0 || g_bwd_variant == 69 || g_bwd_variant == 690) && P == kPT && S < (1 << 23)) {
+        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 695)) && P == kPT && S < (1 << 23)) {
             // region-owned windowed scatter (msda_region.h): one workgroup per tile of the finest level, all query levels.
             // DEFAULT since round 2.  Measured at the 800x1333 encoder shape (backward incl. fill + gather): bs 4 886 us
             // (windowed kernel, variant 65) -> 867 us (16 x 16 regions, 1024 threads, 690) -> 823 us (8 x 16 regions, 512
             // threads, two workgroups per CU); bs 1 248 -> 226 -> 216 us; row atomics 590 MB -> 358 MB (16 x 16).
             const bool small = g_bwd_variant != 690;              // 8 x 16 regions, 512 threads, two workgroups per CU
-            const int rpx = small ? 128 : 256;
+            const int rpx = g_bwd_variant == 692 || g_bwd_variant == 693 ? 64 : (small ? 128 : 256);
             const int rbound = (S + rpx - 1) / rpx * 5 / 4 + 4 * L;
             const int64_t rgrid = (int64_t)N * rbound * M;
             SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
@@ -609,7 +609,12 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                 hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(NT_), rlds, st, grad_out, spatial_shapes, level_start, \
                                    io, S, M, L, rbound, grad_value);                                                    \
             } while (0)
-            if (small) LAUNCH_REG(512, 208, 8, 16, 24, 32);
+            if (g_bwd_variant == 691) LAUNCH_REG(512, 208, 16, 8, 32, 24);          // tuning variants
+            else if (g_bwd_variant == 692) LAUNCH_REG(256, 112, 8, 8, 24, 24);
+            else if (g_bwd_variant == 693) LAUNCH_REG(512, 112, 8, 8, 24, 24);
+            else if (g_bwd_variant == 694) LAUNCH_REG(512, 208, 8, 16, 32, 32);
+            else if (g_bwd_variant == 695) LAUNCH_REG(768, 208, 8, 16, 24, 32);
+            else if (small) LAUNCH_REG(512, 208, 8, 16, 24, 32);
             else LAUNCH_REG(1024, 384, 16, 16, 32, 32);
 #undef LAUNCH_REG
             g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg";
