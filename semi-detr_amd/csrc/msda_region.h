@@ -35,9 +35,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
     const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
 {
     constexpr int kWR = WH * WW, kNE = kRegQ * kPT * 4, SPT = (kRegQ * kPT + NT - 1) / NT, KC = (kWR + NT - 1) / NT;
-    static_assert(kRegQ <= 512 && kWR <= (1 << 14), "entry packing: 9 bits query slot, window row above");
+    static_assert(kRegQ <= 512 && kWR <= (1 << 14), "entry packing: 9 bits query slot (x 128), 14 bits window row, sign bit = last");
     extern __shared__ float4 smem[];
-    float2 *entries = reinterpret_cast<float2 *>(smem);   // [kNE + 8] front: bucketed {weight, last << 30 | window row << 9 | slot};
+    float2 *entries = reinterpret_cast<float2 *>(smem);   // [kNE + 8] front: bucketed {weight, last << 31 | window row << 16 | slot << 7};
                                                           // back: misses {weight, slot << 23 | pixel index}
     float *gtile = reinterpret_cast<float *>(entries + kNE + 8);          // [kRegQ * kD] grad_out rows of the region's queries
     int *cnt = reinterpret_cast<int *>(gtile + kRegQ * kD);
@@ -207,11 +207,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
 #pragma unroll
                     for (int k = 0; k < KC; ++k) {
                         const int j = tid * KC + k;
-                        if (j < kWR) {
-                            start[j] = run;
-                            // element offset of the window row's pixel inside the image slice (only used for touched rows)
-                            rowoff[j] = (st + (y0 + j / WW) * W + x0 + j % WW) * rs;
-                        }
+                        if (j < kWR) start[j] = run;
                         run += cv[k];
                     }
                     if (tid == NT - 1) stats[3] = run;            // total number of bucketed entries
@@ -226,7 +222,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                         const int wr = wrow[sp][cidx];
                         if (wr >= 0)
                             entries[start[wr] + rank[sp][cidx]] = make_float2(
-                                cw[sp][cidx], __int_as_float((rank[sp][cidx] == cnt[wr] - 1 ? (1 << 30) : 0) | (wr << 9) | i));
+                                cw[sp][cidx], __int_as_float((rank[sp][cidx] == cnt[wr] - 1 ? (int)0x80000000 : 0) | (wr << 16) | (i << 7)));
                     }
                 }
                 __syncthreads();
@@ -236,14 +232,21 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                     constexpr int kStreams = NT / 16;
                     const int sid = tid >> 4, l16 = tid & 15;
                     const float2 *gt2 = reinterpret_cast<const float2 *>(gtile);
+                    // entry word: bit 31 = last of its row, bits 16..29 = window row, bits 7..15 = query slot * 128 (= the byte
+                    // offset of the slot's grad_out row in gtile: one and-or gives the lane's address)
+                    const char *gtb = reinterpret_cast<const char *>(gtile) + l16 * 8;
+                    auto gq_of = [&](float y) { return *reinterpret_cast<const float2 *>(gtb + (__float_as_int(y) & 0xff80)); };
                     float *gvs = gvalue + ((int64_t)n * S * M + m) * kD + l16;
                     const int total = stats[3];
                     const int lo = (int)((int64_t)total * sid / kStreams);
                     const int hi = (int)((int64_t)total * (sid + 1) / kStreams);
                     int cur = -1;           // row of the most recent entry whose sum is still open, or -1
                     float2 accv = make_float2(0.f, 0.f);
+                    // window row -> pixel by arithmetic (a table lookup here costs an LDS round trip inside the divergent flush
+                    // branch, with every stream of the wavefront waiting on it)
+                    const int base_pix = st + y0 * W + x0;
                     auto flush = [&](int rowi) {
-                        float *pr = gvs + rowoff[rowi];
+                        float *pr = gvs + (int64_t)(base_pix + (rowi / WW) * W + rowi % WW) * rs;
                         fp_atomic_add(pr, accv.x);
                         fp_atomic_add(pr + 16, accv.y);
                     };
@@ -251,8 +254,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                         const int pk = __float_as_int(en.y);
                         accv.x += en.x * gq.x;
                         accv.y += en.x * gq.y;
-                        cur = (pk >> 9) & 0x1fffff;
-                        if (pk & (1 << 30)) {
+                        cur = (pk >> 16) & 0x3fff;
+                        if (pk < 0) {
                             flush(cur);
                             accv = make_float2(0.f, 0.f);
                             cur = -1;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
 #pragma unroll
                         for (int u = 0; u < 8; ++u) en[u] = entries[e + u];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 511) * 16 + l16];
+                        for (int u = 0; u < 8; ++u) gq[u] = gq_of(en[u].y);
 #pragma unroll
                         for (int u = 0; u < 8; ++u) step(en[u], gq[u]);
                     }
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
 #pragma unroll
                         for (int u = 0; u < 8; ++u) en[u] = entries[min(e + u, hi - 1)];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 511) * 16 + l16];
+                        for (int u = 0; u < 8; ++u) gq[u] = gq_of(en[u].y);
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
                             if (e + u < hi) step(en[u], gq[u]);
