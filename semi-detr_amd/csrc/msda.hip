@@ -533,7 +533,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 695))) {
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 696))) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
@@ -585,7 +585,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                                    grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
         }
-        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 695)) && P == kPT && S < (1 << 23)) {
+        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 696)) && P == kPT && S < (1 << 23)) {
             // region-owned windowed scatter (msda_region.h): one workgroup per tile of the finest level, all query levels.
             // DEFAULT since round 2.  Measured at the 800x1333 encoder shape (backward incl. fill + gather): bs 4 886 us
             // (windowed kernel, variant 65) -> 867 us (16 x 16 regions, 1024 threads, 690) -> 823 us (8 x 16 regions, 512
@@ -609,7 +609,13 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                 hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(NT_), rlds, st, grad_out, spatial_shapes, level_start, \
                                    io, S, M, L, rbound, grad_value);                                                    \
             } while (0)
-            if (g_bwd_variant == 691) LAUNCH_REG(512, 208, 16, 8, 32, 24);          // tuning variants
+            if (g_bwd_variant == 696) {                                             // instrumented build
+                auto kern = &msda_bwd_scatter_d32_reg<IO, 512, 208, 8, 16, 24, 32, 1>;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                const size_t rlds = reg_lds_bytes<512, 208, 24, 32>();
+                hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S,
+                                   M, L, rbound, grad_value);
+            } else if (g_bwd_variant == 691) LAUNCH_REG(512, 208, 16, 8, 32, 24);   // tuning variants
             else if (g_bwd_variant == 692) LAUNCH_REG(256, 112, 8, 8, 24, 24);
             else if (g_bwd_variant == 693) LAUNCH_REG(512, 112, 8, 8, 24, 24);
             else if (g_bwd_variant == 694) LAUNCH_REG(512, 208, 8, 16, 32, 32);

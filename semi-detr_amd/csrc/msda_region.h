@@ -29,7 +29,7 @@ constexpr size_t reg_lds_bytes()
            8 * 4 + (NT / 64) * 4 + 4 * kMaxLevels * 4 + 64;
 }
 
-template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW>
+template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0>
 __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
     const int b = blockIdx.x;
     const int m = (b % M + (b / M) / kScatterHeadRun) % M;
     const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
-    const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // the finest level (most pixels) carries the region grid
     int lb = 0, Hb = (int)shapes[0], Wb = (int)shapes[1];
@@ -63,6 +63,14 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
     (void)lb;
     const int nry = (Hb + RTH - 1) / RTH, nrx = (Wb + RTW - 1) / RTW;
 
+    unsigned long long tmark = DBG ? __builtin_readcyclecounter() : 0ull;      // instrumented build: see msda_dest.h
+    auto lap = [&](int slot_) {
+        if (DBG && tid == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            atomicAdd(&g_dest_dbg[slot_], now - tmark);
+            tmark = now;
+        }
+    };
     for (int reg = slot0; reg < nry * nrx; reg += regions_bound) {
         const int y0b = (reg / nrx) * RTH, x0b = (reg % nrx) * RTW;
         const int y1b = min(y0b + RTH, Hb), x1b = min(x0b + RTW, Wb);
@@ -125,8 +133,29 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                     sm_inv[sp] = 1.f / sum;
                 }
             }
-            for (int r = hw; r < nq; r += NT / 32)      // stage grad_out of the queries, channels (c, c+16) interleaved
-                gtile[r * kD + (c & 15) * 2 + (c >> 4)] = gout[(((int64_t)n * Lq + qlist[r]) * M + m) * kD + c];
+            {   // stage grad_out of the queries, channels (c, c+16) interleaved; every load of a thread is issued before its
+                // stores (a load -> store loop exposed the global latency once per 16 rows: 18 % of the kernel)
+                constexpr int kPass = (kRegQ * 8 + NT - 1) / NT;               // float4 pieces per thread
+                float4 v[kPass];
+#pragma unroll
+                for (int ps = 0; ps < kPass; ++ps) {
+                    const int r = (tid >> 3) + ps * (NT / 8);
+                    v[ps] = r < nq ? *reinterpret_cast<const float4 *>(gout + (((int64_t)n * Lq + qlist[r]) * M + m) * kD + 4 * (tid & 7))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int ps = 0; ps < kPass; ++ps) {
+                    const int r = (tid >> 3) + ps * (NT / 8), c0 = 4 * (tid & 7);
+                    if (r < nq) {
+                        float *dst = gtile + r * kD;
+                        dst[((c0 + 0) & 15) * 2 + ((c0 + 0) >> 4)] = v[ps].x;
+                        dst[((c0 + 1) & 15) * 2 + ((c0 + 1) >> 4)] = v[ps].y;
+                        dst[((c0 + 2) & 15) * 2 + ((c0 + 2) >> 4)] = v[ps].z;
+                        dst[((c0 + 3) & 15) * 2 + ((c0 + 3) >> 4)] = v[ps].w;
+                    }
+                }
+            }
+            lap(0);                  // 0: region set-up (query list, softmax statistics, grad_out staging)
             for (int l = 0; l < L; ++l) {
                 const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
                 // window: where the region centre maps to on this level, minus half the window
@@ -172,6 +201,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                     }
                 }
                 __syncthreads();                  // counters zeroed, previous level's walk finished
+                lap(1);              // 1: sample geometry (global loads of sampling_loc / attn_weight) + previous walk's tail
                 // ---- bucket the in-window corners by window row (count), list the others as misses
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
@@ -185,6 +215,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                     }
                 }
                 __syncthreads();
+                lap(2);              // 2: count
                 // ---- exclusive scan of the kWR counters -> start[]  (thread t owns counters t*KC .. t*KC + KC - 1)
                 {
                     int cv[KC], v = 0;
@@ -213,7 +244,8 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                     if (tid == NT - 1) stats[3] = run;            // total number of bucketed entries
                 }
                 __syncthreads();
-                // ---- fill the buckets; bit 30 marks the last entry of its row
+                lap(3);              // 3: scan
+                // ---- fill the buckets; the sign bit marks the last entry of its row
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
                     const int i = (tid + sp * NT) / P;
@@ -226,6 +258,7 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                     }
                 }
                 __syncthreads();
+                lap(4);              // 4: fill
                 // ---- owner computes: 64 streams of 16 lanes (lane l = channels l and l+16) each walk an equal share of
                 //      the row-sorted entries, running row sum in two registers, one atomic pair per finished row
                 {
@@ -292,7 +325,9 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
                         fp_atomic_add(pr, en.x * g2.x);
                         fp_atomic_add(pr + 16, en.x * g2.y);
                     }
+                    if (DBG && tid == 0) atomicAdd(&g_dest_dbg[10], (unsigned long long)nmiss);
                 }
+                lap(5);              // 5: walk + misses of wave 0 (the other waves' walk ends show up in the next lap 1)
             }
         }
     }
