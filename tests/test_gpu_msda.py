@@ -318,3 +318,32 @@ def test_precondition_errors_match_reference():
         MSDA.ms_deform_attn_forward(v, s.cpu(), ls, lo, a, 64)
     out = MSDA.ms_deform_attn_forward(v, s, ls, lo, a, 3)
     assert out.shape == (3, 5, 64)
+
+
+def test_num_query_equal_spatial_size_without_pixel_queries():
+    """`num_query == spatial_size` alone must not select the self-attention kernels.  Here the value map has
+    five rows more than the levels cover (never sampled) and Lq == S by coincidence: the level table does not tile
+    [0, S), so the front end must not set SEMIDETR_MSDA_QUERIES_ARE_PIXELS, every output row must be written, and the
+    result must match the oracle (the reference op has no coupling between queries and pixels)."""
+    import MultiScaleDeformableAttention as MSDA
+    rng = np.random.default_rng(77)
+    shapes = np.asarray([(6, 9), (3, 5)], np.int64)
+    N, M, D, L, P = 2, 8, 32, 2, 4
+    S = int((shapes[:, 0] * shapes[:, 1]).sum()) + 5
+    Lq = S
+    value = rng.random((N, S, M, D)).astype(np.float32)
+    loc = (rng.random((N, Lq, M, L, P, 2)) * 1.2 - 0.1).astype(np.float32)
+    attn = rng.random((N, Lq, M, L, P)).astype(np.float32)
+    gout = rng.random((N, Lq, M * D)).astype(np.float32)
+    v, s, lo, a, go = _dev(value, shapes, loc, attn, gout)
+    ls = _level_start(s)
+    assert MSDA.pyramid_check(s, ls, S) == 0
+    out = MSDA.ms_deform_attn_forward(v, s, ls, lo, a, 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, s, ls, lo, a, go, 64)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.msda_forward(value, shapes, loc, attn), rtol=0, atol=F32_OUT_ATOL)
+    o_gv, o_gl, o_ga = oracle.msda_backward(value, shapes, loc, attn, gout)
+    np.testing.assert_allclose(gv.cpu().numpy(), o_gv, rtol=0, atol=F32_GRAD_ATOL)
+    np.testing.assert_allclose(gl.cpu().numpy(), o_gl, rtol=1e-5, atol=F32_GRAD_ATOL)
+    np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=1e-5, atol=F32_GRAD_ATOL)
+    assert float(gv[:, -5:].abs().max()) == 0.0        # rows no level covers receive no gradient
