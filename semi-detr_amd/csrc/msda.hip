@@ -533,11 +533,36 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 696))) {
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 697))) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
         if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+        if (g_bwd_variant == 697 && L * P == 16 && P == kPT && S < (1 << 23)) {
+            // experiment: region scatter + gather in ONE launch, roles dealt out in groups of eight workgroups
+            const int rbound = (S + 127) / 128 * 5 / 4 + 4 * L;
+            const int gbound = (S + 31) / 32 * 5 / 4 + 4 * L;
+            const int64_t sblocks = (int64_t)N * rbound * M, gblocks = (int64_t)N * gbound * M, gwgs = (gblocks + 1) / 2;
+            const int64_t sgroups = (sblocks + 7) / 8, ggroups = (gwgs + 7) / 8;
+            const int period = (int)std::max<int64_t>(2, (sgroups + ggroups) / sgroups);
+            const int64_t groups = std::max(sgroups + ggroups, (sgroups - 1) * period + 1);
+            SEMIDETR_REQUIRE(groups * 8 < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+            const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
+            const size_t mlds = std::max(reg_lds_bytes<512, 208, 24, 32>(), 2 * half_f4 * 16);
+            auto kern = &msda_bwd_encreg_merged<IO, 16>;
+            static bool lds_ok = false;
+            if (!lds_ok) {
+                const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                if (ae != hipSuccess) return semidetr::fail((int)ae, "msda_backward: hipFuncSetAttribute: %s", hipGetErrorString(ae));
+                lds_ok = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8)), dim3(512), mlds, st, grad_out, value, spatial_shapes,
+                               level_start, io, S, M, L, P, rbound, (int)sblocks, gbound, (int)gblocks, (int)sgroups, period,
+                               grad_value);
+            g_last_kernels = "fillBufferAligned+msda_bwd_encreg_merged";
+            return semidetr::launch_status("msda_bwd_encreg_merged");
+        }
         if (g_bwd_variant == 68 && L * P == 16 && P == kPT) {
             // Experiment (variant 68): ONE launch, windowed-scatter workgroups interleaved with pairs of gather blocks
             // (msda_bwd_enc_merged).  Measured at bs 4: 1771 us against 879 us for the two launches -- every workgroup of
@@ -585,7 +610,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                                    grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
         }
-        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 696)) && P == kPT && S < (1 << 23)) {
+        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 697)) && P == kPT && S < (1 << 23)) {
             // region-owned windowed scatter (msda_region.h): one workgroup per tile of the finest level, all query levels.
             // DEFAULT since round 2.  Measured at the 800x1333 encoder shape (backward incl. fill + gather): bs 4 886 us
             // (windowed kernel, variant 65) -> 867 us (16 x 16 regions, 1024 threads, 690) -> 823 us (8 x 16 regions, 512

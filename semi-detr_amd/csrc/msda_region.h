@@ -30,13 +30,12 @@ constexpr size_t reg_lds_bytes()
 }
 
 template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0>
-__global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
-    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
-    const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
+__device__ __forceinline__ void reg_scatter_body(
+    const int b, float4 *smem, const float *__restrict__ gout, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
 {
     constexpr int kWR = WH * WW, kNE = kRegQ * kPT * 4, SPT = (kRegQ * kPT + NT - 1) / NT, KC = (kWR + NT - 1) / NT;
     static_assert(kRegQ <= 512 && kWR <= (1 << 14), "entry packing: 9 bits query slot (x 128), 14 bits window row, sign bit = last");
-    extern __shared__ float4 smem[];
     float2 *entries = reinterpret_cast<float2 *>(smem);   // [kNE + 8] front: bucketed {weight, last << 31 | window row << 16 | slot << 7};
                                                           // back: misses {weight, slot << 23 | pixel index}
     float *gtile = reinterpret_cast<float *>(entries + kNE + 8);          // [kRegQ * kD] grad_out rows of the region's queries
@@ -49,7 +48,6 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
 
     constexpr int P = kPT;
     const int Lq = S, LP = L * P, rs = M * kD;
-    const int b = blockIdx.x;
     const int m = (b % M + (b / M) / kScatterHeadRun) % M;
     const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -331,4 +329,42 @@ __global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
             }
         }
     }
+}
+
+template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0>
+__global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    reg_scatter_body<IO, NT, kRegQ, RTH, RTW, WH, WW, DBG>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L,
+                                                          regions_bound, gvalue);
+}
+
+// ONE launch for both halves of the encoder backward (second attempt, after msda_bwd_enc_merged): region-scatter
+// workgroups (LDS / instruction issue / atomics) and pairs of gather blocks (vector-memory path) share the CUs.  Roles
+// are dealt out in GROUPS OF EIGHT consecutive workgroups -- consecutive workgroups go round robin to the 8 XCDs, so
+// "every period-th workgroup scatters" with an even period had put all scatter workgroups on two XCDs.
+template <typename IO, int KLP>
+__global__ __launch_bounds__(512, 4) void msda_bwd_encreg_merged(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int P, int regions_bound, int scatter_blocks,
+    int gather_bound, int gather_blocks, int scatter_groups, int period, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    const int b = (int)blockIdx.x, g = b >> 3, lane8 = b & 7;
+    const bool is_scatter = (g % period == 0) && (g / period < scatter_groups);
+    if (is_scatter) {
+        const int sb = (g / period) * 8 + lane8;
+        if (sb < scatter_blocks)
+            reg_scatter_body<IO, 512, 208, 8, 16, 24, 32>(sb, smem, gout, shapes, starts, io, S, M, L, regions_bound, gvalue);
+        return;
+    }
+    const int ns_before = min((g + period - 1) / period, scatter_groups);       // scatter groups with index < g
+    const int gi = (g - ns_before) * 8 + lane8;                                  // index among the gather workgroups
+    const int half = (int)threadIdx.x >> 8;
+    const int vb = 2 * gi + half;
+    const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
+    gather_body<IO, KLP, 408, true>(vb, (int)threadIdx.x & 255, smem + half * half_f4, vb < gather_blocks, gout, value,
+                                    shapes, starts, io, S, M, L, S, P, gather_bound);
 }
