@@ -533,7 +533,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 697))) {
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 699) || (g_bwd_variant >= 6900 && g_bwd_variant <= 6999))) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
@@ -599,7 +599,16 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             // DINO (L * P == 16): sample loop unrolled, results in registers, 8 x 4 query patches like the forward;
             // measured at the encoder shape, bs 4: generic strips 370 us, unrolled strips 346 us; 66 / 67 force them
             const int gbound = (S + 31) / 32 * 5 / 4 + 4 * L;      // patch grid hint, see launch_fast_forward
-            if (L * P == 16 && g_bwd_variant != 66 && g_bwd_variant != 67)
+            if (L * P == 16 && g_bwd_variant == 6962)            // tuning: 8 loads in flight, 6 waves per SIMD
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, 6, 2>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
+                                   st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
+            else if (L * P == 16 && g_bwd_variant == 6952)       // 8 loads in flight, 5 waves per SIMD
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, 5, 2>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
+                                   st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
+            else if (L * P == 16 && g_bwd_variant == 6948)       // timing aid: nothing stored
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, 4, 104>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
+                                   st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
+            else if (L * P == 16 && g_bwd_variant != 66 && g_bwd_variant != 67)
                 hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
                                    st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
             else if (L * P == 16 && g_bwd_variant == 67)
@@ -610,7 +619,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                                    grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
         }
-        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 697)) && P == kPT && S < (1 << 23)) {
+        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 699) || (g_bwd_variant >= 6900 && g_bwd_variant <= 6999)) && P == kPT && S < (1 << 23)) {
             // region-owned windowed scatter (msda_region.h): one workgroup per tile of the finest level, all query levels.
             // DEFAULT since round 2.  Measured at the 800x1333 encoder shape (backward incl. fill + gather): bs 4 886 us
             // (windowed kernel, variant 65) -> 867 us (16 x 16 regions, 1024 threads, 690) -> 823 us (8 x 16 regions, 512
@@ -620,10 +629,11 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             const int rbound = (S + rpx - 1) / rpx * 5 / 4 + 4 * L;
             const int64_t rgrid = (int64_t)N * rbound * M;
             SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
-#define LAUNCH_REG(NT_, Q_, RH_, RW_, WH_, WW_)                                                                      \
+#define LAUNCH_REG(NT_, Q_, RH_, RW_, WH_, WW_) LAUNCH_REGW(NT_, Q_, RH_, RW_, WH_, WW_, 4)
+#define LAUNCH_REGW(NT_, Q_, RH_, RW_, WH_, WW_, WPE_)                                                                   \
             do {                                                                                                         \
                 static bool lds_ok = false;                                                                              \
-                auto kern = &msda_bwd_scatter_d32_reg<IO, NT_, Q_, RH_, RW_, WH_, WW_>;                                   \
+                auto kern = &msda_bwd_scatter_d32_reg<IO, NT_, Q_, RH_, RW_, WH_, WW_, 0, WPE_>;                                  \
                 if (!lds_ok) {                                                                                           \
                     const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);  \
@@ -645,9 +655,12 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             else if (g_bwd_variant == 693) LAUNCH_REG(512, 112, 8, 8, 24, 24);
             else if (g_bwd_variant == 694) LAUNCH_REG(512, 208, 8, 16, 32, 32);
             else if (g_bwd_variant == 695) LAUNCH_REG(768, 208, 8, 16, 24, 32);
+            else if (g_bwd_variant == 698) LAUNCH_REGW(512, 176, 8, 16, 24, 32, 6);   // three workgroups per CU
+            else if (g_bwd_variant == 699) LAUNCH_REGW(512, 176, 8, 16, 24, 32, 4);   // same LDS, register budget of two
             else if (small) LAUNCH_REG(512, 208, 8, 16, 24, 32);
             else LAUNCH_REG(1024, 384, 16, 16, 32, 32);
 #undef LAUNCH_REG
+#undef LAUNCH_REGW
             g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg";
             return semidetr::launch_status("msda_bwd_scatter_d32_reg");
         }

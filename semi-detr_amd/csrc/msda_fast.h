@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
 // PAIR: two gather blocks share one 512-thread workgroup (merged launches): __syncthreads() is workgroup-wide, so both
 // halves must take the same barriers -- a half that has run out of patches keeps walking, inactive, until the other is
 // done too (decided by __syncthreads_or).
-template <typename IO, int KLP, int PATCH, bool PAIR = false>
+template <typename IO, int KLP, int PATCH, bool PAIR = false, int KB = 4>
 __device__ __forceinline__ void gather_body(
     const int bid, const int tid, float4 *smem, const bool active, const float *__restrict__ gout,
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
@@ -488,7 +488,7 @@ __device__ __forceinline__ void gather_body(
     float4 *rp = rec_p + r * LPP;
     if constexpr (KLP > 0) {
         static_assert(KLP % 8 == 0 && KLP <= 32, "results are spread over the 8 lanes of a group");
-        constexpr int kB = 4;                      // samples per batch: 16 corner loads in flight
+        constexpr int kB = KB % 100;               // samples per batch: 4 -> 16 corner loads in flight
         float4 mine[KLP / 8];
 #pragma unroll
         for (int i = 0; i < KLP / 8; ++i) mine[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -523,8 +523,22 @@ __device__ __forceinline__ void gather_body(
                 pa = group8_sum(pa);
                 px = group8_sum(px);
                 py = group8_sum(py);
-                if ((k & 7) == j) mine[k >> 3] = make_float4(pa, lev_w[l] * px, lev_h[l] * py, a);
+                (void)l;
+                if ((k & 7) == j) {
+                    // a real branch (the empty asm cannot be speculated): as selects, the scheduler hoists all 64 loads of
+                    // the unrolled loop to the top (256 VGPRs, one wave per SIMD) or, capped at 128 VGPRs, spills
+                    asm volatile("");
+                    mine[k >> 3] = make_float4(pa, px, py, a);
+                }
             }
+        }
+        // the W / H factors of grad_sampling_loc once per kept sample, after the loop: an LDS read inside the per-sample
+        // branch put an `s_waitcnt lgkmcnt(0)` on every sample of the unrolled loop
+#pragma unroll
+        for (int i = 0; i < KLP / 8; ++i) {
+            const int l = (j + 8 * i) / P_;
+            mine[i].y *= lev_w[l];
+            mine[i].z *= lev_h[l];
         }
         float dot = 0.f;                           // fused epilogue: sum_k a_k g_k over the row
         if (IO::kSoftmax) {
@@ -532,7 +546,8 @@ __device__ __forceinline__ void gather_body(
             for (int i = 0; i < KLP / 8; ++i) dot += mine[i].w * mine[i].x;
             dot = group8_sum(dot);
         }
-        if (q >= 0) {
+        // KB >= 100: timing aid, results are computed but (practically) never stored
+        if (q >= 0 && (KB < 100 || mine[0].x == 1.2345e30f)) {
             const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
 #pragma unroll
             for (int i = 0; i < KLP / 8; ++i) {
@@ -593,13 +608,13 @@ __device__ __forceinline__ void gather_body(
     }
 }
 
-template <typename IO = LocAttnIO, int KLP = 0, int PATCH = 0>
-__global__ __launch_bounds__(256) void msda_bwd_gather_d32(
+template <typename IO = LocAttnIO, int KLP = 0, int PATCH = 0, int WPE = 4, int KB = 4>
+__global__ __launch_bounds__(256, WPE) void msda_bwd_gather_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
 {
     extern __shared__ float4 smem[];
-    gather_body<IO, KLP, PATCH>((int)blockIdx.x, (int)threadIdx.x, smem, true, gout, value, shapes, starts, io, S, M, L, Lq, P,
+    gather_body<IO, KLP, PATCH, false, KB>((int)blockIdx.x, (int)threadIdx.x, smem, true, gout, value, shapes, starts, io, S, M, L, Lq, P,
                                 tiles_per_image);
 }
 

@@ -25,7 +25,7 @@
 template <int NT, int kRegQ, int WH, int WW>
 constexpr size_t reg_lds_bytes()
 {
-    return (size_t)(kRegQ * kPT * 4 + 8) * 8 + (size_t)kRegQ * kD * 4 + (size_t)3 * WH * WW * 4 + (size_t)kRegQ * 4 +
+    return (size_t)(kRegQ * kPT * 4 + 8) * 8 + (size_t)kRegQ * kD * 4 + (size_t)2 * WH * WW * 4 + (size_t)kRegQ * 4 +
            8 * 4 + (NT / 64) * 4 + 4 * kMaxLevels * 4 + 64;
 }
 
@@ -40,8 +40,8 @@ __device__ __forceinline__ void reg_scatter_body(
                                                           // back: misses {weight, slot << 23 | pixel index}
     float *gtile = reinterpret_cast<float *>(entries + kNE + 8);          // [kRegQ * kD] grad_out rows of the region's queries
     int *cnt = reinterpret_cast<int *>(gtile + kRegQ * kD);
-    int *start = cnt + kWR, *rowoff = start + kWR;
-    int *qlist = rowoff + kWR;                                            // [kRegQ] query index of every slot
+    int *start = cnt + kWR;
+    int *qlist = start + kWR;                                             // [kRegQ] query index of every slot
     int (*stats2)[4] = reinterpret_cast<int (*)[4]>(qlist + kRegQ);
     int *wsum = reinterpret_cast<int *>(stats2 + 2);                      // [NT / 64]
     int *lv = wsum + NT / 64;                                             // [4][kMaxLevels]: y_lo, x_lo, width, slot offset
@@ -107,24 +107,23 @@ __device__ __forceinline__ void reg_scatter_body(
             __syncthreads();
             // this thread's samples = (slot i, point p), sample index tid + sp * NT
             int qs[SPT];
-            int64_t srow[SPT];
+            auto srow_of = [&](int q) { return ((int64_t)n * Lq + q) * M + m; };      // recomputed: two registers fewer per sample
             float sm_max[SPT], sm_inv[SPT];
 #pragma unroll
             for (int sp = 0; sp < SPT; ++sp) {
                 const int sidx = tid + sp * NT, i = sidx / P, p = sidx - i * P;
                 qs[sp] = i < nq ? qlist[i] : -1;
-                srow[sp] = qs[sp] >= 0 ? ((int64_t)n * Lq + qs[sp]) * M + m : 0;
                 sm_max[sp] = 0.f;
                 sm_inv[sp] = 1.f;
                 if (IO::kSoftmax) {      // fused prologue: softmax statistics of the (query, head) row (quad reductions, P == 4)
                     float mx = -__builtin_huge_valf();
                     if (qs[sp] >= 0)
-                        for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow[sp], LP, l * P + p));
+                        for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow_of(qs[sp]), LP, l * P + p));
                     mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
                     mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
                     float sum = 0.f;
                     if (qs[sp] >= 0)
-                        for (int l = 0; l < L; ++l) sum += expf(io.load_w(srow[sp], LP, l * P + p) - mx);
+                        for (int l = 0; l < L; ++l) sum += expf(io.load_w(srow_of(qs[sp]), LP, l * P + p) - mx);
                     sum += __shfl_xor(sum, 1, 64);
                     sum += __shfl_xor(sum, 2, 64);
                     sm_max[sp] = mx;
@@ -164,7 +163,7 @@ __device__ __forceinline__ void reg_scatter_body(
                 for (int k = tid; k < kWR; k += NT) cnt[k] = 0;
                 // ---- this thread's sample geometry: per corner weight, window row (or -1: miss, -2: no corner)
                 float cw[SPT][4];
-                int wrow[SPT][4], rank[SPT][4], pix[SPT][4];
+                int wrow[SPT][4], rank[SPT][4], pixb[SPT];      // pixb: pixel index of the top-left corner (misses only)
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
                     const int sidx = tid + sp * NT, p = sidx % P;
@@ -174,9 +173,10 @@ __device__ __forceinline__ void reg_scatter_body(
                     if (qs[sp] >= 0) {
                         const int k = l * P + p;
                         float x, y;
-                        io.load_xy(srow[sp], (int64_t)n * Lq + qs[sp], LP, k, l, P, H, W, x, y);
+                        const int64_t srow = srow_of(qs[sp]);
+                        io.load_xy(srow, (int64_t)n * Lq + qs[sp], LP, k, l, P, H, W, x, y);
                         if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
-                            a = io.load_w(srow[sp], LP, k);
+                            a = io.load_w(srow, LP, k);
                             if (IO::kSoftmax) a = expf(a - sm_max[sp]) * sm_inv[sp];
                             h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
                             w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
@@ -194,9 +194,9 @@ __device__ __forceinline__ void reg_scatter_body(
                     for (int cidx = 0; cidx < 4; ++cidx) {
                         cw[sp][cidx] = cwv[cidx];
                         wrow[sp][cidx] = off[cidx] < 0 ? -2 : (inw[cidx] ? wr[cidx] : -1);
-                        pix[sp][cidx] = off[cidx] / rs;      // pixel index inside the image (misses only)
                         rank[sp][cidx] = 0;
                     }
+                    pixb[sp] = st + h0 * W + w0;          // a corner that exists (wrow != -2) is this + (c & 1) + (c >> 1) * W
                 }
                 __syncthreads();                  // counters zeroed, previous level's walk finished
                 lap(1);              // 1: sample geometry (global loads of sampling_loc / attn_weight) + previous walk's tail
@@ -209,7 +209,7 @@ __device__ __forceinline__ void reg_scatter_body(
                         if (wrow[sp][cidx] >= 0) rank[sp][cidx] = atomicAdd(&cnt[wrow[sp][cidx]], 1);
                         else if (wrow[sp][cidx] == -1)   // pixel index (< 2^23, checked by the launcher) + slot
                             entries[kNE - 1 - atomicAdd(&stats[1], 1)] = make_float2(
-                                cw[sp][cidx], __int_as_float((int)(((unsigned)i << 23) | (unsigned)pix[sp][cidx])));
+                                cw[sp][cidx], __int_as_float((int)(((unsigned)i << 23) | (unsigned)(pixb[sp] + (cidx & 1) + (cidx >> 1) * W))));
                     }
                 }
                 __syncthreads();
@@ -331,8 +331,8 @@ __device__ __forceinline__ void reg_scatter_body(
     }
 }
 
-template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0>
-__global__ __launch_bounds__(NT, 4) void msda_bwd_scatter_d32_reg(
+template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0, int WPE = 4>
+__global__ __launch_bounds__(NT, WPE) void msda_bwd_scatter_d32_reg(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
 {
