@@ -42,17 +42,42 @@ __device__ __forceinline__ Best combine(const Best &a, const Best &b)
     return r;
 }
 
+// Wave-wide combine without LDS round trips: four DPP steps (quad_perm x2, row_half_mirror, row_mirror) leave every lane of
+// a 16-lane row with its row's result, the four rows are merged through readlane.  (As six `__shfl_xor` rounds of four
+// dwords this reduction was ds_bpermute-latency bound: ~1000 cycles of every Dijkstra step.)
+template <int CTRL>
+__device__ __forceinline__ Best dpp_best(const Best &x)
+{
+    const unsigned long long lb = __builtin_bit_cast(unsigned long long, x.low);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)lb, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(lb >> 32), CTRL, 0xF, 0xF, true);
+    Best o;
+    o.low = __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    o.first = __builtin_amdgcn_update_dpp(0, x.first, CTRL, 0xF, 0xF, true);
+    o.last_un = __builtin_amdgcn_update_dpp(0, x.last_un, CTRL, 0xF, 0xF, true);
+    return o;
+}
+
+__device__ __forceinline__ Best lane_best(const Best &x, int l)
+{
+    const unsigned long long lb = __builtin_bit_cast(unsigned long long, x.low);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)lb, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(lb >> 32), l);
+    Best o;
+    o.low = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    o.first = __builtin_amdgcn_readlane(x.first, l);
+    o.last_un = __builtin_amdgcn_readlane(x.last_un, l);
+    return o;
+}
+
 __device__ __forceinline__ Best wave_best(Best x)
 {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        Best o;
-        o.low = __shfl_xor(x.low, s, 64);
-        o.first = __shfl_xor(x.first, s, 64);
-        o.last_un = __shfl_xor(x.last_un, s, 64);
-        x = combine(x, o);
-    }
-    return x;
+    x = combine(x, dpp_best<0xB1>(x));     // quad_perm [1,0,3,2]
+    x = combine(x, dpp_best<0x4E>(x));     // quad_perm [2,3,0,1]
+    x = combine(x, dpp_best<0x141>(x));    // row_half_mirror
+    x = combine(x, dpp_best<0x140>(x));    // row_mirror: every lane holds its row's result
+    const Best a = combine(lane_best(x, 0), lane_best(x, 16)), c = combine(lane_best(x, 32), lane_best(x, 48));
+    return combine(a, c);
 }
 
 __device__ __forceinline__ int wave_sum_i(int v)
@@ -112,10 +137,33 @@ __global__ __launch_bounds__(64) void lsap_kernel(
 
     // scipy rejects NaN and -inf up front ("matrix contains invalid numeric entries")
     int bad = 0;
-    for (int64_t k = lane; k < (int64_t)nr * nc; k += 64) {
-        const float c = cb[k];
-        if (c != c || c == -__builtin_huge_valf()) bad = 1;
-        if (COST_LDS) cl[k] = c;
+    {
+        // one wavefront reads the whole block (900 x 15 floats = 54 KB for a DINO problem): 16-byte loads, eight in flight
+        // per lane -- as a scalar loop this copy took longer than the solve (211 dependent-latency rounds)
+        const int64_t total = (int64_t)nr * nc;
+        auto check = [&](float c) { if (c != c || c == -__builtin_huge_valf()) bad = 1; };
+        int64_t k = 0;
+        if ((reinterpret_cast<uintptr_t>(cb) & 15) == 0) {
+            const float4 *cb4 = reinterpret_cast<const float4 *>(cb);
+            float4 *cl4 = reinterpret_cast<float4 *>(cl);
+            const int64_t n4 = total / 4;
+            for (int64_t k4 = lane; k4 < n4; k4 += 64 * 8) {
+                float4 c[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) c[t] = k4 + 64 * t < n4 ? cb4[k4 + 64 * t] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    check(c[t].x); check(c[t].y); check(c[t].z); check(c[t].w);
+                    if (COST_LDS && k4 + 64 * t < n4) cl4[k4 + 64 * t] = c[t];
+                }
+            }
+            k = n4 * 4;
+        }
+        for (k += lane; k < total; k += 64) {
+            const float c = cb[k];
+            check(c);
+            if (COST_LDS) cl[k] = c;
+        }
     }
     if (__any(bad)) {
         if (lane == 0) status[b] = 2;
@@ -135,17 +183,19 @@ __global__ __launch_bounds__(64) void lsap_kernel(
             const double ui = u[i];
             const float *crow = (COST_LDS ? cl : cb) + (int64_t)i * si;
             Best best = {kInf, 0x7fffffff, -1};
-            // four list positions per lane and trip: the list-indirected reads (remaining -> cost, v, spc, row4col)
-            // are independent across positions (distinct columns), so they are issued together instead of as
-            // four dependent chains; positions are still consumed in increasing order (the tie rule needs that)
-            for (int it0 = lane; it0 < num_rem; it0 += 256) {
-                int jj[4];
-                double cc[4], vv[4], ss[4];
-                int rr[4];
+            // kScan list positions per lane and trip: the list-indirected reads (remaining -> cost, v, spc, row4col)
+            // are independent across positions (distinct columns), so they are issued together instead of as dependent
+            // chains -- a DINO problem (900 columns) is one trip of two LDS round trips; positions are still consumed in
+            // increasing order (the tie rule needs that)
+            constexpr int kScan = 16;
+            for (int it0 = lane; it0 < num_rem; it0 += 64 * kScan) {
+                int jj[kScan];
+                double cc[kScan], vv[kScan], ss[kScan];
+                int rr[kScan];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) jj[t] = it0 + 64 * t < num_rem ? remaining[it0 + 64 * t] : -1;
+                for (int t = 0; t < kScan; ++t) jj[t] = it0 + 64 * t < num_rem ? remaining[it0 + 64 * t] : -1;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < kScan; ++t) {
                     const int j = jj[t] < 0 ? 0 : jj[t];
                     cc[t] = (double)crow[(int64_t)j * sj];
                     vv[t] = v[j];
@@ -153,7 +203,7 @@ __global__ __launch_bounds__(64) void lsap_kernel(
                     rr[t] = row4col[j];
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < kScan; ++t) {
                     if (jj[t] < 0) break;
                     const int it = it0 + 64 * t, j = jj[t];
                     const double r = min_val + cc[t] - ui - vv[t];
