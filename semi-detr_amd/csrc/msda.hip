@@ -485,6 +485,37 @@ int launch_strips_backward(hipStream_t st, size_t fill, const float *grad_out, c
         g_last_kernels = "fillBufferAligned+msda_bwd_lvl_merged";
         return semidetr::launch_status("msda_bwd_lvl_merged");
     }
+    if (g_bwd_variant == 901 && P <= 8) {
+        // experiment: NO memset -- the gather launch zero-fills grad_value as a side job, the level-aggregated scatter
+        // follows as its own launch
+        int chunks = (Lq + kLvlQ - 1) / kLvlQ;
+        const int want = (128 + N * L * M - 1) / (N * L * M);
+        chunks = std::max(chunks, std::min(want, (Lq + 63) / 64));
+        const int chunk_q = (Lq + chunks - 1) / chunks;
+        const int gt = (Lq + 31) / 32;
+        const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
+        SEMIDETR_REQUIRE(fill % 16 == 0, SEMIDETR_E_BADARG, "msda_backward: grad_value size not a multiple of 16 bytes");
+        if (L * P == 16)
+            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
+                               grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt,
+                               reinterpret_cast<float4 *>(grad_value), (int64_t)(fill / 16));
+        else
+            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
+                               grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt,
+                               reinterpret_cast<float4 *>(grad_value), (int64_t)(fill / 16));
+        if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
+        const size_t slds = (size_t)kLvlQ * kD * 4 + ((size_t)chunk_q * P * 4 + 8) * 8 + (size_t)2 * kLvlRows * 4;
+        static bool lds_ok = false;
+        if (!lds_ok) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_scatter_d32_lvl<IO>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+            lds_ok = true;
+        }
+        hipLaunchKernelGGL((msda_bwd_scatter_d32_lvl<IO>), dim3((unsigned)((int64_t)N * chunks * L * M)), dim3(kLvlThreads), slds, st,
+                           grad_out, spatial_shapes, level_start, io, S, M, L, Lq, P, chunks, chunk_q, grad_value);
+        g_last_kernels = "msda_bwd_gather_d32+msda_bwd_scatter_d32_lvl";
+        return semidetr::launch_status("msda_bwd_scatter_d32_lvl");
+    }
     const bool fused = g_bwd_variant != 808 && g_bwd_variant != 832;
     if (fused) {
         hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
@@ -536,8 +567,18 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 699) || (g_bwd_variant >= 6900 && g_bwd_variant <= 6999))) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
-        hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
-        if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+        // the unrolled gather launch clears grad_value as a side job (no hipMemsetAsync): the scatter that accumulates into it
+        // is the NEXT launch.  Measured (tools/r02_fillgather_try.sh): encoder bs 4 774 -> 766 us, bs 1 204 -> 201 us; 6991
+        // forces the memset.  (The same idea for arbitrary query sets -- gather + fill, then the level scatter as a second
+        // launch, variant 901 -- loses against the merged launch: micro-benchmark 36.2 -> 41-44 us, decoder bs 4 161 -> 169.)
+        const bool gather_kernel_runs = !(g_bwd_variant == 697 || g_bwd_variant == 68);
+        const bool fill_in_gather = L * P == 16 && gather_kernel_runs && g_bwd_variant != 6991 && g_bwd_variant != 66 &&
+                                    g_bwd_variant != 67 && g_bwd_variant != 6962 && g_bwd_variant != 6952 && g_bwd_variant != 6948 &&
+                                    (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0;
+        if (!fill_in_gather) {
+            hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
+            if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+        }
         if (g_bwd_variant == 697 && L * P == 16 && P == kPT && S < (1 << 23)) {
             // experiment: region scatter + gather in ONE launch, roles dealt out in groups of eight workgroups
             const int rbound = (S + 127) / 128 * 5 / 4 + 4 * L;
@@ -608,6 +649,10 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             else if (L * P == 16 && g_bwd_variant == 6948)       // timing aid: nothing stored
                 hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, 4, 104>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
                                    st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
+            else if (fill_in_gather)
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
+                                   st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound,
+                                   reinterpret_cast<float4 *>(grad_value), (int64_t)(fill / 16));
             else if (L * P == 16 && g_bwd_variant != 66 && g_bwd_variant != 67)
                 hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
                                    st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
@@ -661,7 +706,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             else LAUNCH_REG(1024, 384, 16, 16, 32, 32);
 #undef LAUNCH_REG
 #undef LAUNCH_REGW
-            g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg";
+            g_last_kernels = fill_in_gather ? "msda_bwd_gather_d32+msda_bwd_scatter_d32_reg" : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg";
             return semidetr::launch_status("msda_bwd_scatter_d32_reg");
         }
         // grad_value: destination-owned tiles (msda_dest.h) unless a windowed variant is forced (64..67) or the pyramid
@@ -687,7 +732,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             else
                 hipLaunchKernelGGL((msda_bwd_dest_d32<IO, 16, 16, 8>), dim3((unsigned)grid), dim3(kDestThreads), 0, st,
                                    grad_out, spatial_shapes, level_start, io, S, M, L, P, bound, grad_value);
-            g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_dest_d32";
+            g_last_kernels = fill_in_gather ? "msda_bwd_gather_d32+msda_bwd_dest_d32" : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_dest_d32";
             return semidetr::launch_status("msda_bwd_dest_d32");
         }
         // windowed (source-owned) kernel: patches are enumerated on the device (the level table lives in device
@@ -720,7 +765,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             hipLaunchKernelGGL((msda_bwd_scatter_d32_win<IO, 8, 16, 24, 32>), dim3((unsigned)grid), dim3(kWinThreads),
                                wlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, tiles_bound, grad_value);
         }
-        g_last_kernels = "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_win";
+        g_last_kernels = fill_in_gather ? "msda_bwd_gather_d32+msda_bwd_scatter_d32_win" : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_win";
         return semidetr::launch_status("msda_bwd_scatter_d32_win");
     }
     // rows per workgroup: 32 normally, 8 when the problem is too small to fill 256 CUs with 32-row tiles

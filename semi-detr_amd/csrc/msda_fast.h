@@ -611,9 +611,17 @@ __device__ __forceinline__ void gather_body(
 template <typename IO = LocAttnIO, int KLP = 0, int PATCH = 0, int WPE = 4, int KB = 4>
 __global__ __launch_bounds__(256, WPE) void msda_bwd_gather_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image,
+    float4 *__restrict__ zero = nullptr, int64_t zero_n4 = 0)
 {
     extern __shared__ float4 smem[];
+    // optional side job: zero-fill `zero_n4` float4s (grad_value, which the scatter launch that FOLLOWS accumulates into) --
+    // every workgroup clears one contiguous slice with fire-and-forget stores before its gather work
+    if (zero) {
+        const int64_t per = (zero_n4 + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < zero_n4 ? lo + per : zero_n4;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     gather_body<IO, KLP, PATCH, false, KB>((int)blockIdx.x, (int)threadIdx.x, smem, true, gout, value, shapes, starts, io, S, M, L, Lq, P,
                                 tiles_per_image);
 }
