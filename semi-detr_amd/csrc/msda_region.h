@@ -152,7 +152,7 @@ __device__ __forceinline__ void reg_scatter_body(
                     }
                 }
             }
-            lap(0);                  // 0: region set-up (query list, softmax statistics, grad_out staging)
+            lap(0);                  // 0: region set-up (query list, softmax statistics, sampling data, grad_out staging)
             for (int l = 0; l < L; ++l) {
                 const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
                 // window: where the region centre maps to on this level, minus half the window
@@ -164,19 +164,29 @@ __device__ __forceinline__ void reg_scatter_body(
                 // ---- this thread's sample geometry: per corner weight, window row (or -1: miss, -2: no corner)
                 float cw[SPT][4];
                 int wrow[SPT][4], rank[SPT][4], pixb[SPT];      // pixb: pixel index of the top-left corner (misses only)
+                // every global load of the level first, unconditionally (an empty slot reads slot 0's row) instead of four
+                // serial load -> test -> load round trips.  The wait that follows also drains the wave's row atomics of the
+                // previous level (28 % of wave 0's cycles in the instrumented build); loading all levels before the level loop
+                // and forcing them to arrive there removes that wait (geometry 28 -> 4 %, count 18 -> 5 %) but the time moves
+                // into the walk (37 -> 51 %) and the next region's set-up (9 -> 23 %): 449 us either way -- what the waves wait
+                // for is the atomic path itself, wherever the wait is placed
+                float gx[SPT], gy[SPT], ga[SPT];
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
-                    const int sidx = tid + sp * NT, p = sidx % P;
+                    const int k = l * P + (tid + sp * NT) % P, qq = qs[sp] >= 0 ? qs[sp] : qlist[0];
+                    const int64_t srow = srow_of(qq);
+                    io.load_xy(srow, (int64_t)n * Lq + qq, LP, k, l, P, H, W, gx[sp], gy[sp]);
+                    ga[sp] = io.load_w(srow, LP, k);
+                }
+#pragma unroll
+                for (int sp = 0; sp < SPT; ++sp) {
                     int off[4] = {-1, -1, -1, -1};
                     float lw = 0.f, lh = 0.f, a = 0.f;
                     int h0 = 0, w0 = 0;
                     if (qs[sp] >= 0) {
-                        const int k = l * P + p;
-                        float x, y;
-                        const int64_t srow = srow_of(qs[sp]);
-                        io.load_xy(srow, (int64_t)n * Lq + qs[sp], LP, k, l, P, H, W, x, y);
+                        const float x = gx[sp], y = gy[sp];
                         if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
-                            a = io.load_w(srow, LP, k);
+                            a = ga[sp];
                             if (IO::kSoftmax) a = expf(a - sm_max[sp]) * sm_inv[sp];
                             h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
                             w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
@@ -198,8 +208,9 @@ __device__ __forceinline__ void reg_scatter_body(
                     }
                     pixb[sp] = st + h0 * W + w0;          // a corner that exists (wrow != -2) is this + (c & 1) + (c >> 1) * W
                 }
+                lap(6);              // 6: sample geometry (global loads of sampling_loc / attn_weight)
                 __syncthreads();                  // counters zeroed, previous level's walk finished
-                lap(1);              // 1: sample geometry (global loads of sampling_loc / attn_weight) + previous walk's tail
+                lap(1);              // 1: waiting for the other waves' walk of the previous level
                 // ---- bucket the in-window corners by window row (count), list the others as misses
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {

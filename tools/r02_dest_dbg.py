@@ -14,9 +14,9 @@ MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, gout, 64); torch.cuda.synchro
 lib.semidetr_debug_counters(ctypes.cast(buf, ctypes.c_void_p), 1)
 MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, gout, 64); torch.cuda.synchronize()
 lib.semidetr_debug_counters(ctypes.cast(buf, ctypes.c_void_p), 1)
-names = (["setup", "geometry", "count", "scan", "fill", "walk", "", "", "", "", "misses_n", ""] if len(sys.argv) > 1 and sys.argv[1] == "696"
+names = (["setup", "walk_tail_wait", "count", "scan", "fill", "walk", "geometry", "", "", "", "misses_n", ""] if len(sys.argv) > 1 and sys.argv[1] == "696"
          else ["enumerate", "sort", "walk", "misses", "tail", "flush", "", "", "rounds", "entries", "misses_n", "units"])
-tot = sum(buf[i] for i in range(6))
+tot = sum(buf[i] for i in range(7))
 for i, nme in enumerate(names):
-    if nme: print(f"{nme:10s} {buf[i]:16d}" + (f"  {100.0*buf[i]/tot:5.1f}% of workgroup cycles" if i < 6 else ""))
+    if nme: print(f"{nme:10s} {buf[i]:16d}" + (f"  {100.0*buf[i]/tot:5.1f}% of workgroup cycles" if i < 7 else ""))
 print("entries/round", buf[9] / max(1, buf[8]), "rounds/unit", buf[8] / max(1, buf[11]), "cycles/round", tot / max(1, buf[8]))
