@@ -25,7 +25,7 @@ def main():
     bad = {"nms": 0, "o2m": 0, "lsap": 0}
     for case in range(a.cases):
         # ---- NMS
-        B, Q, C = int(rng.integers(1, 4)), int(rng.integers(1, 700)), int(rng.integers(1, 60))
+        B, Q, C = int(rng.integers(1, 4)), int(rng.integers(1, 1500 if case % 4 == 0 else 700)), int(rng.integers(1, 60))
         logits = rng.normal(rng.uniform(-6, 1), rng.uniform(0.5, 3), (B, Q, C)).astype(np.float32)
         if rng.random() < 0.3:
             logits = (np.round(logits * 8) / 8).astype(np.float32)
