@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 #include "msda_fast.h"   // IO policies + the D == 32 fp32 kernels
 #include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
 #include "msda_region.h" // region-owned windowed scatter for encoder self-attention
+#include "msda_lw.h"     // LDS-window forward for encoder self-attention
 
 int g_fwd_variant = 0, g_bwd_variant = 0;
 
@@ -337,6 +338,17 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
 #define LAUNCH_FWD(SP, UN, PT, TILES)                                                                       \
     hipLaunchKernelGGL((msda_fwd_d32<SP, UN, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        lds, st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
+    if constexpr (!IO::kSoftmax) {
+        if (g_fwd_variant == 600 && pixels && L * P == 16 && P == kPT) {
+            // LDS-window forward (msda_lw.h): 8 x 8 query patches, three workgroups per CU
+            const int bound = (S + 63) / 64 * 5 / 4 + 4 * L;
+            SEMIDETR_REQUIRE((int64_t)N * bound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
+            hipLaunchKernelGGL((msda_fwd_d32_lw<IO>), dim3((unsigned)(N * bound * M)), dim3(256), lw_lds_bytes(), st, value,
+                               spatial_shapes, level_start, io, S, M, L, bound, out);
+            g_last_kernels = "msda_fwd_d32_lw";
+            return semidetr::launch_status("msda_fwd_d32_lw");
+        }
+    }
     if (g_fwd_variant >= 500 && g_fwd_variant <= 505) {
         SEMIDETR_REQUIRE(pixels, SEMIDETR_E_BADARG, "msda_forward: the resident-level kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS");
         // 500: 8 patches per workgroup, coarse levels resident; 501: same schedule, nothing resident (control);

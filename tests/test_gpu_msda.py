@@ -124,7 +124,7 @@ def test_fast_path_generic_heads_levels_points(M, L, P):
     ([(20, 27), (20, 27), (19, 26)], 4, 4, "near"),             # levels of (almost) equal size: a 16 x 16 region of the
                                                                 # finest level holds ~760 queries -> several passes
 ])
-@pytest.mark.parametrize("variant", [(0, 0), (1, 32), (2, 832), (408, 64), (216, 65), (804, 66), (0, 67), (500, 70), (500, 71), (0, 68), (0, 69), (0, 690), (0, 697), (0, 698)])
+@pytest.mark.parametrize("variant", [(0, 0), (1, 32), (2, 832), (408, 64), (216, 65), (804, 66), (0, 67), (500, 70), (500, 71), (0, 68), (0, 69), (0, 690), (0, 697), (0, 698), (600, 0)])
 def test_encoder_self_attention_vs_oracle(shapes, M, P, mode, variant):
     """num_query == spatial_size selects the patch-tiled forward and (with num_point == 4) the gather +
     owner-computes scatter backward (variant 0); (1, 32) forces the plain kernels on the same inputs; the
