@@ -47,8 +47,8 @@ const char *semidetr_last_error(void);
  *   out / grad_out (batch, num_query, num_heads * channels)
  * Semantics: bilinear sampling with align_corners=False pixel mapping (h = y*H - 0.5), zero padding,
  * a sample contributes only if -1 < h < H and -1 < w < W.  forward writes every element of `out`.
- * backward zero-fills grad_value itself (hipMemsetAsync on `stream`), accumulates into it with fp
- * atomics, and writes every element of grad_sampling_loc / grad_attn_weight.
+ * backward zero-fills grad_value itself (on `stream`: hipMemsetAsync, or as a side job of its first kernel),
+ * accumulates into it with fp atomics, and writes every element of grad_sampling_loc / grad_attn_weight.
  * The whole batch is one launch (the reference's im2col_step chunking does not change results).
  * f32: fast path for channels == 32, generic path otherwise.  f64: generic path (gradcheck parity).
  *
