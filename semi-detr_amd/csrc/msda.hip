@@ -687,10 +687,11 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             const int64_t rgrid = (int64_t)N * rbound * M;
             SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
 #define LAUNCH_REG(NT_, Q_, RH_, RW_, WH_, WW_) LAUNCH_REGW(NT_, Q_, RH_, RW_, WH_, WW_, 4)
-#define LAUNCH_REGW(NT_, Q_, RH_, RW_, WH_, WW_, WPE_)                                                                   \
+#define LAUNCH_REGW(NT_, Q_, RH_, RW_, WH_, WW_, WPE_) LAUNCH_REGU(NT_, Q_, RH_, RW_, WH_, WW_, WPE_, 8)
+#define LAUNCH_REGU(NT_, Q_, RH_, RW_, WH_, WW_, WPE_, WU_)                                                                   \
             do {                                                                                                         \
                 static bool lds_ok = false;                                                                              \
-                auto kern = &msda_bwd_scatter_d32_reg<IO, NT_, Q_, RH_, RW_, WH_, WW_, 0, WPE_>;                                  \
+                auto kern = &msda_bwd_scatter_d32_reg<IO, NT_, Q_, RH_, RW_, WH_, WW_, 0, WPE_, WU_>;                                  \
                 if (!lds_ok) {                                                                                           \
                     const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                      \
                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);  \
@@ -714,10 +715,13 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             else if (g_bwd_variant == 695) LAUNCH_REG(768, 208, 8, 16, 24, 32);
             else if (g_bwd_variant == 698) LAUNCH_REGW(512, 176, 8, 16, 24, 32, 6);   // three workgroups per CU
             else if (g_bwd_variant == 699) LAUNCH_REGW(512, 176, 8, 16, 24, 32, 4);   // same LDS, register budget of two
+            else if (g_bwd_variant == 6981) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 4);    // walk unrolled by 4
+            else if (g_bwd_variant == 6982) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 16);   // ... by 16
             else if (small) LAUNCH_REG(512, 208, 8, 16, 24, 32);
             else LAUNCH_REG(1024, 384, 16, 16, 32, 32);
 #undef LAUNCH_REG
 #undef LAUNCH_REGW
+#undef LAUNCH_REGU
             g_last_kernels = fill_in_gather ? "msda_bwd_gather_d32+msda_bwd_scatter_d32_reg" : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg";
             return semidetr::launch_status("msda_bwd_scatter_d32_reg");
         }

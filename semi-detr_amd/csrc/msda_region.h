@@ -29,7 +29,7 @@ constexpr size_t reg_lds_bytes()
            8 * 4 + (NT / 64) * 4 + 4 * kMaxLevels * 4 + 64;
 }
 
-template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0>
+template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0, int WU = 8>
 __device__ __forceinline__ void reg_scatter_body(
     const int b, float4 *smem, const float *__restrict__ gout, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
@@ -304,23 +304,23 @@ __device__ __forceinline__ void reg_scatter_body(
                         }
                     };
                     int e = lo;
-                    for (; e + 8 <= hi; e += 8) {
-                        float2 en[8], gq[8];
+                    for (; e + WU <= hi; e += WU) {
+                        float2 en[WU], gq[WU];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) en[u] = entries[e + u];
+                        for (int u = 0; u < WU; ++u) en[u] = entries[e + u];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) gq[u] = gq_of(en[u].y);
+                        for (int u = 0; u < WU; ++u) gq[u] = gq_of(en[u].y);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) step(en[u], gq[u]);
+                        for (int u = 0; u < WU; ++u) step(en[u], gq[u]);
                     }
-                    if (e < hi) {       // tail of < 8 entries
-                        float2 en[8], gq[8];
+                    if (e < hi) {       // tail of < WU entries
+                        float2 en[WU], gq[WU];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) en[u] = entries[min(e + u, hi - 1)];
+                        for (int u = 0; u < WU; ++u) en[u] = entries[min(e + u, hi - 1)];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) gq[u] = gq_of(en[u].y);
+                        for (int u = 0; u < WU; ++u) gq[u] = gq_of(en[u].y);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
+                        for (int u = 0; u < WU; ++u)
                             if (e + u < hi) step(en[u], gq[u]);
                     }
                     if (cur >= 0) flush(cur);
@@ -342,13 +342,13 @@ __device__ __forceinline__ void reg_scatter_body(
     }
 }
 
-template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0, int WPE = 4>
+template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0, int WPE = 4, int WU = 8>
 __global__ __launch_bounds__(NT, WPE) void msda_bwd_scatter_d32_reg(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
 {
     extern __shared__ float4 smem[];
-    reg_scatter_body<IO, NT, kRegQ, RTH, RTW, WH, WW, DBG>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L,
+    reg_scatter_body<IO, NT, kRegQ, RTH, RTW, WH, WW, DBG, WU>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L,
                                                           regions_bound, gvalue);
 }
 
