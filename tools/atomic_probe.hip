@@ -5,6 +5,8 @@
 //   mode 2: 16 lanes per row, lane j adds dwords 2j,2j+1 (2 instructions, stride-8B lanes)
 //   mode 4: like 1 but workgroup-scope atomics (executed in the XCD-local L2; only valid when one XCD owns the row)
 //   mode 5: like 1 but with rows partitioned by XCD (row % 8 == HW XCC_ID), workgroup scope -- the safe form
+//   mode 6: like 2 but only ONE of the wave's four 16-lane groups is active per instruction (the region scatter's flushes:
+//           a stream reaches a row end while its three neighbours do not) -- same rows, 4x the wave-instructions
 //   mode 3: like 0 but the 4 dwords are written lane-transposed: instr k, lane j -> dword 8k+j (contiguous 32B)
 // build: hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics tools/atomic_probe.hip -o /tmp/atomic_probe
 #include <hip/hip_runtime.h>
@@ -17,7 +19,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k(float *buf, unsigned rows, int per_thread_rows, unsigned locality)
 {
     const unsigned tid = blockIdx.x * 256 + threadIdx.x;
-    constexpr int LPR = MODE == 0 || MODE == 3 ? 8 : (MODE == 1 || MODE >= 4 ? 32 : 16);
+    constexpr int LPR = MODE == 0 || MODE == 3 ? 8 : (MODE == 1 || MODE == 4 || MODE == 5 ? 32 : 16);
     unsigned xcc = 0;
     if (MODE == 5) { xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7; }
     const unsigned grp = tid / LPR, j = tid % LPR;
@@ -32,6 +34,10 @@ __global__ __launch_bounds__(256) void k(float *buf, unsigned rows, int per_thre
         else if (MODE == 4) { __hip_atomic_fetch_add(p + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
         else if (MODE == 5) { float *pp = buf + (size_t)((r & ~7u) | xcc) % rows * 32; __hip_atomic_fetch_add(pp + j, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
         else if (MODE == 2) { unsafeAtomicAdd(p + 2 * j, v); unsafeAtomicAdd(p + 2 * j + 1, v); }
+        else if (MODE == 6) {
+            for (int turn = 0; turn < 4; ++turn)
+                if (((tid >> 4) & 3) == (unsigned)turn) { unsafeAtomicAdd(p + j, v); unsafeAtomicAdd(p + 16 + j, v); }
+        }
         else { unsafeAtomicAdd(p + j, v); unsafeAtomicAdd(p + 8 + j, v); unsafeAtomicAdd(p + 16 + j, v); unsafeAtomicAdd(p + 24 + j, v); }
     }
 }
@@ -46,8 +52,8 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (unsigned loc : {0u, 64u}) {
-        for (int mode = 0; mode < 6; ++mode) {
-            const int lpr = mode == 0 || mode == 3 ? 8 : (mode == 1 || mode >= 4 ? 32 : 16);
+        for (int mode = 0; mode < 7; ++mode) {
+            const int lpr = mode == 0 || mode == 3 ? 8 : (mode == 1 || mode == 4 || mode == 5 ? 32 : 16);
             const int per = 16;
             const long groups = total_row_updates / per;
             const long threads = groups * lpr;
@@ -61,6 +67,7 @@ int main(int argc, char **argv)
                 if (mode == 3) k<3><<<blocks, 256>>>(buf, rows, per, loc);
                 if (mode == 4) k<4><<<blocks, 256>>>(buf, rows, per, loc);
                 if (mode == 5) k<5><<<blocks, 256>>>(buf, rows, per, loc);
+                if (mode == 6) k<6><<<blocks, 256>>>(buf, rows, per, loc);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 hipEventElapsedTime(&ms, e0, e1);
