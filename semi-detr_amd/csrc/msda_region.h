@@ -288,6 +288,7 @@ __device__ __forceinline__ void reg_scatter_body(
                     // branch, with every stream of the wavefront waiting on it)
                     const int base_pix = st + y0 * W + x0;
                     auto flush = [&](int rowi) {
+                        if (DBG && l16 == 0) atomicAdd(&g_dest_dbg[12 + (l < 4 ? l : 3)], 1ull);      // flushed rows by sampling level
                         float *pr = gvs + (int64_t)(base_pix + (rowi / WW) * W + rowi % WW) * rs;
                         fp_atomic_add(pr, accv.x);
                         fp_atomic_add(pr + 16, accv.y);

@@ -19,4 +19,6 @@ names = (["setup", "walk_tail_wait", "count", "scan", "fill", "walk", "geometry"
 tot = sum(buf[i] for i in range(7))
 for i, nme in enumerate(names):
     if nme: print(f"{nme:10s} {buf[i]:16d}" + (f"  {100.0*buf[i]/tot:5.1f}% of workgroup cycles" if i < 7 else ""))
+if len(sys.argv) > 1 and sys.argv[1] == "696":
+    print("rows flushed by sampling level 0..3:", [int(buf[12 + i]) for i in range(4)], "misses", int(buf[10]))
 print("entries/round", buf[9] / max(1, buf[8]), "rounds/unit", buf[8] / max(1, buf[11]), "cycles/round", tot / max(1, buf[8]))
