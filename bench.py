@@ -721,14 +721,16 @@ def main():
             "roofline_l1": {"bound": "l1_return", "kernel": fwd_name, "kernel_symbols": wl.kernels.get(fwd_name, []),
                             "achieved": corner_bytes / fdur / 1e9, "peak": l1_peak, "unit": "GB/s",
                             "frac": corner_bytes / fdur / 1e9 / l1_peak,
-                            "frac_at_observed_clock": corner_bytes / fdur / 1e9 / (256 * 64 * 1720e6 / 1e9),
+                            "frac_at_observed_clock": corner_bytes / fdur / 1e9 / (256 * 64 * 2190e6 / 1e9),
+                            "observed_clock_mhz": 2190.0, "ta_busy_frac_pmc": 0.80,
                             "note": "corner rows (4 x 128 B per sample) / launch time vs 256 CU x 64 B/clk x 2400 MHz; "
-                                    "the engine clock under this load was measured at ~1.72 GHz (per-workgroup cycle counter, "
-                                    "DESIGN.md 6) -> frac_at_observed_clock.  This vector-memory INSTRUCTION path (16 cycles "
-                                    "per 64-lane buffer_load_dwordx4, whether or not the data comes from the cache: "
-                                    "tools/r02_oob_probe.py) is what binds the forward and the gather; taking accesses off "
-                                    "it through LDS cost more in occupancy than it returned "
-                                    "(profiles/r02_fwd_resident_level_pmc.txt)",
+                                    "observed clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time and TA busy = TA_BUSY_avr / "
+                                    "active cycles from profiles/r02_fwd_enc_TA.txt (rocprofv3 --pmc, same kernel, probe "
+                                    "inputs).  This vector-memory INSTRUCTION path (16 cycles per 64-lane "
+                                    "buffer_load_dwordx4: 450 k cycles per CU and launch = 84 % of the kernel at that clock) "
+                                    "is what binds the forward and the gather; taking accesses off it through LDS cost more "
+                                    "than it returned three times (DESIGN.md 2.1, profiles/r02_fwd_resident_level_pmc.txt, "
+                                    "profiles/r02_lds_window_forward.txt)",
                             "corner_bytes_per_launch": corner_bytes, "device_clock_mhz_reported": clock_mhz},
             "rooflines_all_msda_groups": {k: {"frac_hbm_peak": roofline_of(k)["frac"], "avg_launch_us": roofline_of(k)["avg_launch_us"],
                                               "kernels": wl.kernels.get(k, [])} for k in sorted(msda)},
