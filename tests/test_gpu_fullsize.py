@@ -3,7 +3,7 @@
   * encoder self-attention at bs 4 (N=4, Lq = S = 22 223: 28 288-workgroup patch forward, patch gather, destination-
     owned / windowed scatter with head rotation across 4 images) -- the reference contract (LocAttnIO) AND the fused
     prologue/epilogue (RawIO) -- against the CPU oracle, every element;
-  * the five-level full-size shape (S = 22 300, Lq = 900, bs 2);
+  * the five-level full-size shape (S = 22 300, Lq = 900, bs 2) and the five-level ENCODER (Lq = S = 22 300, bs 2);
   * decoder size at bs 4 with de-noising padding (Lq = 1100).
 
 The oracle (plain C restatement pinned to the reference's Python by tests/golden) takes a few seconds per case here.
@@ -117,6 +117,32 @@ def test_encoder_bs4_wide_offsets_vs_oracle():
     torch.cuda.synchronize()
     np.testing.assert_allclose(gv.cpu().numpy(), o_gv, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gv).max())))
     np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
+
+
+def test_encoder_five_levels_full_size_vs_oracle():
+    """The COCO-Full recipe's pyramid (five feature levels, S = 22 300, BASELINE.json configs[3]) as ENCODER self-attention:
+    L * P = 20, so the forward takes the patch kernel with a runtime sample loop, the backward the generic-loop gather + the
+    region-owned scatter with five sampling levels.  N = 2, every element against the oracle."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd  # noqa: F401
+    N, levels = 2, LEVELS + [(7, 11)]
+    value, shp, ref, off, logits, gout = _encoder_case(N, levels, 2.0, 13)
+    loc, attn = _prologue_np(ref, off, logits, shp, P)
+    o_out = oracle.msda_forward(value, shp, loc, attn)
+    o_gv, o_gl, o_ga = oracle.msda_backward(value, shp, loc, attn, gout)
+    tsh = _t(shp)
+    tls = _starts(tsh)
+    out = MSDA.ms_deform_attn_forward(_t(value), tsh, tls, _t(loc), _t(attn), 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(_t(value), tsh, tls, _t(loc), _t(attn), _t(gout), 64)
+    torch.cuda.synchronize()
+    _check(out.cpu().numpy(), gv.cpu().numpy(), o_out, o_gv)
+    np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(gl.cpu().numpy(), o_gl, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gl).max())))
+    # the fused prologue / epilogue on the same inputs
+    out2 = MSDA.ms_deform_attn_fused_forward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits))
+    gv2, _, _ = MSDA.ms_deform_attn_fused_backward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits), _t(gout))
+    torch.cuda.synchronize()
+    _check(out2.cpu().numpy(), gv2.cpu().numpy(), o_out, o_gv)
 
 
 @pytest.mark.parametrize("name,levels,N,Lq", [("five_level_bs2_Lq900", LEVELS + [(7, 11)], 2, 900),
