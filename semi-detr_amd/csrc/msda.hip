@@ -497,6 +497,53 @@ int launch_strips_backward(hipStream_t st, size_t fill, const float *grad_out, c
         g_last_kernels = "fillBufferAligned+msda_bwd_lvl_merged";
         return semidetr::launch_status("msda_bwd_lvl_merged");
     }
+    if (g_bwd_variant == 902 && P <= 8 && (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0) {
+        // EXPERIMENT: cooperative zero fill inside the merged launch (msda_bwd_lvl_coop), no hipMemsetAsync.  The three
+        // counters of a launch live in a library-owned device buffer (64 slots handed out round robin; the kernel leaves its
+        // slot zeroed).  Not capturable on its first call (hipMalloc), not meant for concurrent replays of one captured graph.
+        static unsigned *sync_buf = nullptr;
+        static int sync_dev = -1, next_slot = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!sync_buf || dev != sync_dev) {
+            unsigned *p = nullptr;
+            hipError_t e = hipMalloc(&p, 64 * 4 * sizeof(unsigned));
+            if (e == hipSuccess) e = hipMemset(p, 0, 64 * 4 * sizeof(unsigned));
+            if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward: sync buffer: %s", hipGetErrorString(e));
+            sync_buf = p;
+            sync_dev = dev;
+        }
+        unsigned *slot = sync_buf + 4 * (next_slot++ & 63);
+        int chunks = (Lq + kLvlQ - 1) / kLvlQ;
+        const int want = (128 + N * L * M - 1) / (N * L * M);
+        chunks = std::max(chunks, std::min(want, (Lq + 63) / 64));
+        const int chunk_q = (Lq + chunks - 1) / chunks;
+        const int gt = (Lq + 31) / 32;
+        const int64_t gblocks = (int64_t)N * gt * M, sblocks = (int64_t)N * chunks * L * M;
+        const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
+        const size_t slds = std::max((size_t)kLvlQ * kD * 4 + ((size_t)chunk_q * P * 4 + 8) * 8 + (size_t)2 * kLvlRows * 4,
+                                     2 * half_f4 * 16);
+        const int64_t grid = sblocks + (gblocks + 1) / 2;
+        SEMIDETR_REQUIRE(grid < INT32_MAX && slds <= 159 * 1024, SEMIDETR_E_TOOLARGE, "msda_backward: merged launch too large");
+#define LAUNCH_COOP(KLP_)                                                                                            \
+        do {                                                                                                             \
+            static bool lds_ok = false;                                                                                  \
+            if (!lds_ok) {                                                                                               \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_lvl_coop<IO, KLP_>),                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);                      \
+                lds_ok = true;                                                                                           \
+            }                                                                                                            \
+            hipLaunchKernelGGL((msda_bwd_lvl_coop<IO, KLP_>), dim3((unsigned)grid), dim3(kLvlThreads), slds, st, grad_out,   \
+                               value, spatial_shapes, level_start, io, S, M, L, Lq, P, chunks, chunk_q, (int)sblocks, gt, \
+                               (int)gblocks, grad_value, reinterpret_cast<float4 *>(grad_value), (int64_t)(fill / 16),  \
+                               slot, 1 << 20);                                                                         \
+        } while (0)
+        if (L * P == 16) LAUNCH_COOP(16);
+        else LAUNCH_COOP(0);
+#undef LAUNCH_COOP
+        g_last_kernels = "msda_bwd_lvl_coop";
+        return semidetr::launch_status("msda_bwd_lvl_coop");
+    }
     if (g_bwd_variant == 901 && P <= 8) {
         // experiment: NO memset -- the gather launch zero-fills grad_value as a side job, the level-aggregated scatter
         // follows as its own launch

@@ -33,7 +33,7 @@
 
 constexpr int kDestThreads = 512;
 // instrumented build (DBG == 2): per-phase cycle counts summed over workgroups, read back by semidetr_debug_counters
-__device__ unsigned long long g_dest_dbg[16];
+// g_dest_dbg[16] (debug / instrumentation counters read by semidetr_debug_counters) is defined in msda_fast.h
 constexpr int kDestMaxLevels = 8;        // LDS tables of the kernel (pyramids with more levels take the windowed kernel)
 
 template <typename IO, int TH, int TW, int R, int DBG = 0>

@@ -95,6 +95,9 @@ struct RawIO {
 // ---------------------------------------------------------------------------------------------
 constexpr int kD = 32;
 
+// debug / instrumentation counters of the experimental kernels (semidetr_debug_counters reads and resets them)
+__device__ unsigned long long g_dest_dbg[16];
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x)
 {
@@ -1086,11 +1089,17 @@ constexpr int kLvlThreads = 512;
 constexpr int kLvlQ = 256;               // queries per workgroup
 constexpr int kLvlRows = 4352;           // largest level that is bucketed (counters: 2 x 17 KB of LDS)
 
-template <typename IO>
+struct NoWait {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// `before_atomics` runs (all threads) right before the first row atomic: the cooperative-fill launch waits there for the
+// zero fill of grad_value (msda_bwd_lvl_coop)
+template <typename IO, typename Wait = NoWait>
 __device__ __forceinline__ void lvl_scatter_body(
     int b, float4 *smem, const float *__restrict__ gout, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int chunks, int chunk_q,
-    float *__restrict__ gvalue)
+    float *__restrict__ gvalue, const Wait before_atomics = Wait())
 {
     constexpr int NT = kLvlThreads, kStreams = NT / 16;
     // layout: gtile [kLvlQ * 32 floats] | entries [emax float2] | cnt [kLvlRows] | start [kLvlRows]
@@ -1239,6 +1248,7 @@ __device__ __forceinline__ void lvl_scatter_body(
         }
     }
     __syncthreads();
+    before_atomics();
     // ---- walk: 32 streams of 16 lanes (lane = channels l16 and l16 + 16), equal shares, one atomic pair per row run
     {
         const int sid = tid >> 4, l16 = tid & 15;
@@ -1318,4 +1328,79 @@ __global__ __launch_bounds__(kLvlThreads) void msda_bwd_lvl_merged(
     const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;       // LDS of one gather block, in float4
     gather_body<IO, KLP, 0>(vb, (int)threadIdx.x & 255, smem + half * half_f4, vb < gather_blocks, gout, value, shapes,
                             starts, io, S, M, L, Lq, P, gather_tiles);
+}
+
+// EXPERIMENT (backward variant 902): the merged launch WITHOUT the hipMemsetAsync in front of it.  Roles are dealt out by an
+// atomic TICKET taken when a workgroup starts (not by blockIdx, so nothing depends on the dispatch order): the first
+// ceil(gather_blocks / 2) tickets zero a slice of grad_value each, release it (agent-scope fence: the lines leave the XCD's
+// L2 -- the row atomics are performed memory-side), count themselves done and run the gather; every later ticket is a scatter
+// workgroup, which sorts its samples as usual and only then -- right before its first row atomic -- waits for the done
+// count.  Whoever holds a scatter ticket knows that all fillers already RUN (they drew their tickets earlier) and fillers
+// never wait for anything: no co-residency assumption, no deadlock.  The wait is bounded anyway (`spin_limit` polls, then
+// it proceeds and raises g_dest_dbg[15] -- results are wrong in that case, a hang is worse).  The last workgroup to finish
+// zeroes the three counters, so a slot is clean again when the kernel ends.
+struct FillWait {
+    const unsigned *done;
+    unsigned need;
+    int spin_limit;
+    __device__ __forceinline__ void operator()() const
+    {
+        if (threadIdx.x == 0) {
+            int it = 0;
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                if (++it >= spin_limit) { atomicAdd(&g_dest_dbg[15], 1ull); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+    }
+};
+
+template <typename IO, int KLP>
+__global__ __launch_bounds__(kLvlThreads) void msda_bwd_lvl_coop(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int chunks, int chunk_q,
+    int scatter_blocks, int gather_tiles, int gather_blocks, float *__restrict__ gvalue, float4 *__restrict__ zero,
+    int64_t zero_n4, unsigned *__restrict__ sync, int spin_limit)
+{
+    extern __shared__ float4 smem[];
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&sync[0], 1u);
+    __syncthreads();
+    const unsigned ticket = s_ticket, fillers = (unsigned)(gather_blocks + 1) / 2;
+    if (ticket < fillers) {
+        const int64_t per = (zero_n4 + fillers - 1) / fillers;
+        const int64_t lo = (int64_t)ticket * per, hi = lo + per < zero_n4 ? lo + per : zero_n4;
+        // write-through stores (sc0 sc1): the zeros go to memory, where the row atomics are performed, without the L2
+        // write-back an agent-scope release fence costs (buffer_wbl2 of the whole XCD L2 per wave: 36 -> 87 us at the
+        // micro-benchmark shape); vmcnt(0) = written
+        {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f z = {0.f, 0.f, 0.f, 0.f};
+            for (int64_t i = lo + threadIdx.x; i < hi; i += kLvlThreads) {
+                float4 *dst = zero + i;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(z) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&sync[1], 1u);
+        const int half = (int)threadIdx.x >> 8;
+        const int vb = 2 * (int)ticket + half;
+        const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
+        gather_body<IO, KLP, 0>(vb, (int)threadIdx.x & 255, smem + half * half_f4, vb < gather_blocks, gout, value, shapes,
+                                starts, io, S, M, L, Lq, P, gather_tiles);
+    } else if ((int)(ticket - fillers) < scatter_blocks) {
+        lvl_scatter_body<IO, FillWait>((int)(ticket - fillers), smem, gout, shapes, starts, io, S, M, L, Lq, P, chunks, chunk_q,
+                                       gvalue, FillWait{sync + 1, fillers, spin_limit});
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned f = atomicAdd(&sync[2], 1u);
+        if (f == gridDim.x - 1) {        // last one out: every ticket is drawn, every filler counted
+            atomicExch(&sync[0], 0u);
+            atomicExch(&sync[1], 0u);
+            atomicExch(&sync[2], 0u);
+        }
+    }
 }
