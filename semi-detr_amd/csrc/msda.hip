@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 #include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
 #include "msda_region.h" // region-owned windowed scatter for encoder self-attention
 #include "msda_lw.h"     // LDS-window forward for encoder self-attention
+#include "msda_rw.h"     // region-window forward / gather for encoder self-attention
 
 int g_fwd_variant = 0, g_bwd_variant = 0;
 
@@ -320,6 +321,71 @@ int pick_split(int forced, int N, int Lq, int M)
     return 4;
 }
 
+
+// ---- region-window kernels (msda_rw.h): one launcher for the forward and the gather -------------------------------
+// dynamic LDS above 64 KB has to be allowed per kernel AND per device
+template <typename K>
+int allow_big_lds(K kern, const char *what)
+{
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess && dev != done_dev) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) done_dev = dev;
+    }
+    if (e != hipSuccess) return semidetr::fail((int)e, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+    return SEMIDETR_OK;
+}
+
+template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GATHER, int DBG = 0, int TUNE = 42>
+int launch_rw(hipStream_t st, const float *grad_out, const float *value, const int64_t *spatial_shapes,
+              const int64_t *level_start, const IO &io, int N, int S, int M, float *out, float4 *zero, int64_t zero_n4)
+{
+    auto kern = &msda_rw_d32<IO, NT, RTH, RTW, H0, HC, KL, GATHER, DBG, TUNE>;
+    if (int rc = allow_big_lds(kern, "msda region-window kernel")) return rc;
+    // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
+    // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
+    const int rpx = RTH * RTW;
+    const int bound = ((S * 3 / 4 + rpx - 1) / rpx) * 9 / 8 + 2 * KL;
+    const int64_t grid = (int64_t)N * bound * M;
+    SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda: grid too large");
+    constexpr size_t lds = rw_lds_bytes<NT, RTH, RTW, H0, HC, KL>();
+    static_assert(lds <= 160 * 1024, "region-window configuration does not fit the LDS");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, grad_out, value, spatial_shapes, level_start, io, S, M,
+                       bound, out, zero, zero_n4);
+    return semidetr::launch_status(GATHER ? "msda_rw_d32<gather>" : "msda_rw_d32<forward>");
+}
+
+// variant code -> configuration {threads, region, margins}; 0 = the default configuration
+template <typename IO, int KL, bool GATHER>
+int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *value, const int64_t *spatial_shapes,
+                  const int64_t *level_start, const IO &io, int N, int S, int M, float *out, float4 *zero, int64_t zero_n4)
+{
+#define RW(NT_, RH_, RW_, H0_, HC_) RWT(NT_, RH_, RW_, H0_, HC_, 0, 42)
+#define RWT(NT_, RH_, RW_, H0_, HC_, DBG_, TUNE_) \
+    launch_rw<IO, NT_, RH_, RW_, H0_, HC_, KL, GATHER, DBG_, TUNE_>(st, grad_out, value, spatial_shapes, level_start, io, N, S, M, out, zero, zero_n4)
+    if constexpr (KL == 4) {
+        switch (cfg) {
+        case 0: return RWT(512, 8, 16, 4, 5, 0, 40);
+        case 1: if constexpr (!GATHER) return RWT(256, 16, 16, -1, 4, 0, 40); else break;
+        case 2: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 0, 40); else break;
+        case 3: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 3, 0, 40); else break;
+        case 4: if constexpr (!GATHER) return RWT(256, 8, 8, -1, 4, 0, 40); else break;
+        case 5: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 0, 40); else break;      // level 0 through global loads
+        case 6: if constexpr (!GATHER) return RWT(512, 8, 16, -1, 5, 0, 40); else break;
+        case 7: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 1, 40); else return RWT(512, 8, 16, 4, 5, 1, 40);
+        case 8: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 2, 40); else return RWT(512, 8, 16, 4, 5, 2, 40);
+        case 9: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 3, 40); else return RWT(512, 8, 16, 4, 5, 3, 40);
+        default: break;
+        }
+    }
+    if constexpr (KL == 4) return RWT(512, 8, 16, 4, 5, 0, 40);
+    else return RWT(512, 8, 16, 4, 4, 0, 40);      // five levels: the margin-5 windows do not fit 160 KB
+#undef RWT
+#undef RW
+}
+
 // ---- fast-path launchers, shared by the reference contract (LocAttnIO) and the fused prologue (RawIO) ----
 template <typename IO>
 int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spatial_shapes,
@@ -348,6 +414,14 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             g_last_kernels = "msda_fwd_d32_lw";
             return semidetr::launch_status("msda_fwd_d32_lw");
         }
+    }
+    if (g_fwd_variant >= 700 && g_fwd_variant <= 709) {
+        SEMIDETR_REQUIRE(pixels && P == kPT && (L == 4 || L == 5), SEMIDETR_E_BADARG,
+                         "msda_forward: the region-window kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, 4 or 5 levels");
+        g_last_kernels = "msda_rw_d32<forward>";
+        if (L == 4)
+            return launch_rw_cfg<IO, 4, false>(g_fwd_variant - 700, st, nullptr, value, spatial_shapes, level_start, io, N, S, M, out, nullptr, 0);
+        return launch_rw_cfg<IO, 5, false>(0, st, nullptr, value, spatial_shapes, level_start, io, N, S, M, out, nullptr, 0);
     }
     if (g_fwd_variant >= 500 && g_fwd_variant <= 505) {
         SEMIDETR_REQUIRE(pixels, SEMIDETR_E_BADARG, "msda_forward: the resident-level kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS");
@@ -623,15 +697,16 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     const bool win_ok = P == kPT;
-    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 699) || (g_bwd_variant >= 6900 && g_bwd_variant <= 6999))) {
+    if ((pixels && S < (1 << 24) && win_ok && g_bwd_variant == 0) || ((g_bwd_variant >= 64 && g_bwd_variant <= 74) || (g_bwd_variant >= 690 && g_bwd_variant <= 699) || (g_bwd_variant >= 6900 && g_bwd_variant <= 7009))) {
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         // the unrolled gather launch clears grad_value as a side job (no hipMemsetAsync): the scatter that accumulates into it
         // is the NEXT launch.  Measured (tools/r02_fillgather_try.sh): encoder bs 4 774 -> 766 us, bs 1 204 -> 201 us; 6991
         // forces the memset.  (The same idea for arbitrary query sets -- gather + fill, then the level scatter as a second
         // launch, variant 901 -- loses against the merged launch: micro-benchmark 36.2 -> 41-44 us, decoder bs 4 161 -> 169.)
+        const bool rw_gather = g_bwd_variant >= 7000 && g_bwd_variant <= 7009 && P == kPT && (L == 4 || L == 5);
         const bool gather_kernel_runs = !(g_bwd_variant == 697 || g_bwd_variant == 68);
-        const bool fill_in_gather = L * P == 16 && gather_kernel_runs && g_bwd_variant != 6991 && g_bwd_variant != 66 &&
+        const bool fill_in_gather = (L * P == 16 || rw_gather) && gather_kernel_runs && g_bwd_variant != 6991 && g_bwd_variant != 66 &&
                                     g_bwd_variant != 67 && g_bwd_variant != 6962 && g_bwd_variant != 6952 && g_bwd_variant != 6948 &&
                                     (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0;
         if (!fill_in_gather) {
@@ -693,6 +768,14 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             g_last_kernels = "fillBufferAligned+msda_bwd_enc_merged";
             return semidetr::launch_status("msda_bwd_enc_merged");
         }
+        if (rw_gather) {   // gather half through the region windows (msda_rw.h)
+            float4 *z = fill_in_gather ? reinterpret_cast<float4 *>(grad_value) : nullptr;
+            const int rc = L == 4 ? launch_rw_cfg<IO, 4, true>(g_bwd_variant - 7000, st, grad_out, value, spatial_shapes, level_start,
+                                                               io, N, S, M, nullptr, z, (int64_t)(fill / 16))
+                                  : launch_rw_cfg<IO, 5, true>(0, st, grad_out, value, spatial_shapes, level_start, io, N, S, M,
+                                                               nullptr, z, (int64_t)(fill / 16));
+            if (rc) return rc;
+        } else
         {   // gather half: the two small gradients, streams like the forward
             const int gt = (Lq + 31) / 32;
             const size_t glds = (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
@@ -723,7 +806,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                                    grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
             if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
         }
-        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 699) || (g_bwd_variant >= 6900 && g_bwd_variant <= 6999)) && P == kPT && S < (1 << 23)) {
+        if ((g_bwd_variant == 0 || (g_bwd_variant >= 69 && g_bwd_variant <= 69) || (g_bwd_variant >= 690 && g_bwd_variant <= 699) || (g_bwd_variant >= 6900 && g_bwd_variant <= 7009)) && P == kPT && S < (1 << 23)) {
             // region-owned windowed scatter (msda_region.h): one workgroup per tile of the finest level, all query levels.
             // DEFAULT since round 2.  Measured at the 800x1333 encoder shape (backward incl. fill + gather): bs 4 886 us
             // (windowed kernel, variant 65) -> 867 us (16 x 16 regions, 1024 threads, 690) -> 823 us (8 x 16 regions, 512
@@ -769,7 +852,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
 #undef LAUNCH_REG
 #undef LAUNCH_REGW
 #undef LAUNCH_REGU
-            g_last_kernels = fill_in_gather ? "msda_bwd_gather_d32+msda_bwd_scatter_d32_reg" : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg";
+            g_last_kernels = rw_gather ? "msda_rw_d32<gather>+msda_bwd_scatter_d32_reg" : (fill_in_gather ? "msda_bwd_gather_d32+msda_bwd_scatter_d32_reg" : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg");
             return semidetr::launch_status("msda_bwd_scatter_d32_reg");
         }
         // grad_value: destination-owned tiles (msda_dest.h) unless a windowed variant is forced (64..67) or the pyramid

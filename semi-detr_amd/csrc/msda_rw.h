@@ -1,0 +1,604 @@
+// Encoder self-attention with the value rows served from REGION WINDOWS in LDS (fp32, D == 32, num_point == 4):
+// forward (msda_rw_d32<..., false>) and the gather half of the backward (<..., true>: grad_sampling_loc /
+// grad_attn_weight, optionally clearing grad_value for the scatter launch that follows).  Included by msda.hip after
+// msda_fast.h / msda_region.h.
+//
+// Why.  The patch kernels (msda_fwd_d32<1,4,408>, msda_bwd_gather_d32) pull every corner row through the vector-memory
+// path: 4 x 22223 x 8 heads x 16 samples x 4 corners x 128 B = 5.8 GB per bs-4 launch at 64 B/clk/CU -- TA busy 80 %,
+// 0.18 of the HBM roofline, and a load that never touches the cache costs almost as much as a real one
+// (profiles/r02_fwd_enc_TA.txt).  LDS reads run at 256 B/clk/CU (ds_read_b128), four times that rate, but a window only
+// pays when many corner reads share it.  Three earlier attempts staged one window per (query patch of ONE level,
+// sampling level): ~3 reads per staged row, a barrier pair and a dependent load -> geometry -> record chain per level,
+// coarse-level patches whose footprint on the fine levels never fits -- all slower than the plain kernel.
+//
+// Here the unit of work is a REGION of the image, as in the region-owned scatter (msda_region.h): a workgroup owns an
+// RTH x RTW tile of the finest level and ONE head and takes the queries of ALL levels whose pixel centres lie in it
+// (128 + 32 + 8 + 2 for a halving pyramid).  Their samples on level l all fall around the same spot, so one window per
+// sampling level, staged ONCE per region for all levels together, serves every query of the region: ~10 corner reads per
+// staged row, one barrier between staging and compute, no per-level phases.
+//   * staging: every thread issues all its 16-byte pieces as buffer loads (rows outside a level arrive as zeros through
+//     the bounds check, which IS the op's zero padding, so the compute loop needs no per-corner validity at all), then
+//     stores them with ds_write_b128.  (buffer_load ... lds was tried first: the DMA path sustains ~13 B/clk/CU here,
+//     84 us of a 330 us launch.)
+//   * 8 lanes per query, 8 queries per wavefront: lane j does the geometry of samples j, j + 8 (all lanes busy), the
+//     records {4 corner weights} + {two window offsets} go through a per-octet LDS scratch that only the owning wave
+//     touches (no workgroup barrier); in the compute loop the octet reads the four corner rows with two address
+//     registers and the window pitch of the sample's level as an immediate, 8 lanes x float4 per row;
+//   * bank conflicts: ds_read_b128 is served in groups of 16 lanes = half-rows of 4 different octets (A.first, B.second,
+//     C.second, D.first -- MI355X_MICROARCH.md, LDS table); a 128-byte row covers half of the 64 banks, so A / D (and
+//     B / C) collide iff their rows have equal parity.  All window widths are odd (left / right and top / bottom
+//     neighbours differ in parity), octets A, B read their sample's corners in the order even, odd, odd, even, octets
+//     C, D in the order odd, even, even, odd: conflict-free by construction;
+//   * a sample whose footprint leaves its window (or any sampling pattern the windows were not sized for) takes the
+//     plain kernel's path at the end of the query's round: global corner loads through the same buffer resource.  Any
+//     input is correct; locality only decides speed.  A round in which more than a third of the samples fall outside is
+//     processed entirely that way (the windows were staged in vain, nothing worse).
+// Queries are enumerated from the level table exactly like the region scatter (by(qy) = ((2 qy + 1) Hb) / (2 Hq) is
+// monotone: every level contributes an exact rectangle, every query belongs to exactly one region), so the kernels need
+// SEMIDETR_MSDA_QUERIES_ARE_PIXELS and num_levels == KL.
+#pragma once
+
+constexpr int kRwHeadRun = 16;      // head rotation of the region kernels (see tile_of_block)
+
+// Window geometry at compile time.  Level l of a halving pyramid sees the region as (RTH >> l) x (RTW >> l) pixels;
+// H0 / HC = margin in pixels around it on level 0 / on the coarser levels (whose pixel centres are not aligned with
+// the region's edges: one more row / column).  Widths are rounded up to odd (bank parity, see above).
+template <int RTH, int RTW, int H0, int HC, int KL>
+struct RwWin {
+    __host__ __device__ static constexpr int ext(int r, int l) { return (r >> l) < 1 ? 1 : (r >> l); }
+    __host__ __device__ static constexpr int wh(int l) { return ext(RTH, l) + (l ? 2 * HC + 1 : 2 * H0); }
+    __host__ __device__ static constexpr int ww(int l) { return (ext(RTW, l) + (l ? 2 * HC + 1 : 2 * H0)) | 1; }
+    static constexpr bool fine_global = H0 < 0;           // level 0 has no window: its samples are loaded from global memory
+    __host__ __device__ static constexpr int rows(int l) { return (l == 0 && H0 < 0) ? 0 : wh(l) * ww(l); }
+    __host__ __device__ static constexpr int row0(int l)      // first row of level l's window: even (parity bookkeeping)
+    {
+        int s = 0;
+        for (int i = 0; i < l; ++i) s += (rows(i) + 1) & ~1;
+        return s;
+    }
+    __host__ __device__ static constexpr int maxww()
+    {
+        int w = 0;
+        for (int i = (H0 < 0 ? 1 : 0); i < KL; ++i) w = ww(i) > w ? ww(i) : w;
+        return w;
+    }
+    static constexpr int zrow = row0(KL);                 // even.  Rows [zrow, zrow + zrows) are zeros: a sample that is not
+    static constexpr int zrows = (maxww() + 2 + 1) & ~1;  // served from its window reads rows zrow (+1) and those + its pitch
+    static constexpr int total = zrow + zrows;
+};
+
+template <int KL, bool FG = false>
+constexpr int rw_oct_bytes()      // per octet: KLP x {float4 record} | KLP x {two 16-bit window offsets} | two 32-byte slots (+ bank spread)
+{
+    constexpr int raw = KL * kPT * 20 + 64 + (FG ? kPT * 32 : 0);
+    return raw + (raw % 128 == 0 ? 16 : 0);      // octet pitch: A, B, C, D on distinct banks
+}
+
+template <int NT, int RTH, int RTW, int H0, int HC, int KL>
+constexpr size_t rw_lds_bytes()
+{
+    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)(NT / 8) * rw_oct_bytes<KL, (H0 < 0)>();
+}
+
+// smallest q in [0, nq] with ((2 q + 1) * nb) / (2 * nq) >= bound  (the first pixel of a level with nq rows whose centre
+// maps into row >= bound of the nb-row grid level).  32-bit division unless the product needs more (levels > 32767 wide).
+__device__ __forceinline__ int rw_first(int bound, int nq, int nb)
+{
+    const unsigned long long a = 2ull * (unsigned)nq * (unsigned)bound;
+    unsigned cc;                                      // ceil(a / nb): 2 q + 1 >= cc
+    if ((a + (unsigned)nb) >> 32) cc = (unsigned)((a + (unsigned)nb - 1u) / (unsigned)nb);
+    else cc = ((unsigned)a + (unsigned)nb - 1u) / (unsigned)nb;
+    return min(nq, (int)(cc >> 1));
+}
+
+// DBG (tuning builds only): 1 = per-phase cycle counts of wave 0 into g_dest_dbg, 2 = windows not staged (results
+// wrong, timing aid), 3 = compute loop skipped (results wrong, timing aid)
+// TUNE = 10 * (compute-loop steps between scheduling barriers) + (out-of-window samples per octet whose loads are issued
+// ahead of the compute loop)
+template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GATHER, int DBG = 0, int TUNE = 42>
+__global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(      // 256-thread workgroups: two per CU
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int regions_bound, float *__restrict__ out,
+    float4 *__restrict__ zero, int64_t zero_n4)
+{
+    using Wn = RwWin<RTH, RTW, H0, HC, KL>;
+    constexpr int P = kPT, KLP = KL * P, G = NT / 8, NPASS = (KLP + 7) / 8;
+    constexpr bool FG = Wn::fine_global;                  // level 0 through global loads (forward only)
+    static_assert(!FG || !GATHER, "the gather keeps a window for every level");
+    constexpr int kOctBytes = rw_oct_bytes<KL, FG>();
+    constexpr int kOffAt = KLP * 16, kSlotAt = KLP * 20, kFineAt = KLP * 20 + 64;
+    static_assert(Wn::total * 128 <= (1 << 20), "window offsets are kept in 16 bits, in units of 16 bytes");
+    constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
+    static_assert(P == 4 && KLP <= 32, "lane j of an octet owns samples j, j + 8, ...");
+    static_assert(kOctBytes % 16 == 0, "records are read with ds_read_b128");
+
+    extern __shared__ float4 smem[];
+    char *const lds = reinterpret_cast<char *>(smem);
+    char *const recs = lds + Wn::total * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int oc = tid >> 3, j8 = tid & 7;
+    const int cls = (tid >> 4) & 1;                       // octets C, D of each 32-lane half read odd rows first
+    const int Lq = S, rs = M * kD;
+    const int b = (int)blockIdx.x;
+    unsigned long long tmark = DBG == 1 ? __builtin_readcyclecounter() : 0ull;
+    auto lap = [&](int slot_) {
+        if (DBG == 1 && tid == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            atomicAdd(&g_dest_dbg[slot_], now - tmark);
+            tmark = now;
+        }
+    };
+    const int m = (b % M + (b / M) / kRwHeadRun) % M;
+    const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
+
+    if (GATHER && zero) {      // side job: clear grad_value, which the scatter launch that FOLLOWS accumulates into
+        const int64_t per = (zero_n4 + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < zero_n4 ? lo + per : zero_n4;
+        for (int64_t i = lo + tid; i < hi; i += NT) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // Per-level data lives in lanes 0 .. KL-1 of every wave (r_*): wave-uniform copies come from readlane with a constant
+    // lane, per-lane selections from __shfl with the level as the source lane.  (Select chains over small arrays are
+    // turned into dynamically indexed scratch accesses by the compiler -- and a scratch load waits for vmcnt.)
+    const int r_H = lane < KL ? (int)shapes[2 * lane] : 1, r_W = lane < KL ? (int)shapes[2 * lane + 1] : 1;
+    const int r_st = lane < KL ? (int)starts[lane] : 0;
+    int r_wh = 1, r_ww = 1, r_row0 = 0;          // window geometry of level `lane` (compile-time values, lane-selected)
+#pragma unroll
+    for (int l = 0; l < KL; ++l)
+        if (lane == l) { r_wh = Wn::wh(l); r_ww = Wn::ww(l); r_row0 = Wn::row0(l); }
+    int Hs[KL], Ws[KL], sts[KL];
+#pragma unroll
+    for (int l = 0; l < KL; ++l) {
+        Hs[l] = __builtin_amdgcn_readlane(r_H, l);
+        Ws[l] = __builtin_amdgcn_readlane(r_W, l);
+        sts[l] = __builtin_amdgcn_readlane(r_st, l);
+    }
+    // the region grid lives on level 0 (the finest level of a DETR pyramid; any order is correct, the windows are sized
+    // for this one)
+    const int Hb = Hs[0], Wb = Ws[0];
+    const int nry = (Hb + RTH - 1) / RTH, nrx = (Wb + RTW - 1) / RTW;
+
+    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)n * S * M * kD, (unsigned)S * M * kD * 4u);
+    const unsigned lane_b = (unsigned)(m * kD + 4 * j8) * 4u;
+    const unsigned row_bytes = (unsigned)rs * 4u;
+
+    // the level of this lane's sample in pass p (sample k = j8 + 8 p, level k / 4) and its static constants
+    int myl[NPASS], myH[NPASS], myW[NPASS], myst[NPASS], my_wh1[NPASS], my_ww1[NPASS], my_ww[NPASS], my_row0[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int l = min((j8 + 8 * p) / P, KL - 1);
+        myl[p] = l;
+        myH[p] = __shfl(r_H, l, 64);
+        myW[p] = __shfl(r_W, l, 64);
+        myst[p] = __shfl(r_st, l, 64);
+        my_wh1[p] = __shfl(r_wh, l, 64) - 1;
+        my_ww[p] = __shfl(r_ww, l, 64);
+        my_ww1[p] = my_ww[p] - 1;
+        my_row0[p] = __shfl(r_row0, l, 64);
+    }
+
+    char *const orec = recs + oc * kOctBytes;             // this octet's records
+    const char *const wbase = lds + j8 * 16;
+
+    for (int reg = slot0; reg < nry * nrx; reg += regions_bound) {
+        const int y0b = (reg / nrx) * RTH, x0b = (reg % nrx) * RTW;
+        const int y1b = min(y0b + RTH, Hb), x1b = min(x0b + RTW, Wb);
+        // ---- the region's queries: on level lq an exact rectangle (lanes 0 .. KL-1 of every wave work it out; the counts
+        //      become wave-uniform through readlane, the rest is fetched per lane with __shfl: no LDS table, no barrier)
+        int r_ylo = 0, r_xlo = 0, r_w = 1, r_cnt = 0;
+        float r_invw = 1.f;
+        // window origins: where the region centre maps to on each level, minus half the window
+        const float pcy = (y0b + 0.5f * RTH) / (float)Hb, pcx = (x0b + 0.5f * RTW) / (float)Wb;
+        const int r_wy0 = (int)floorf(pcy * (float)r_H - 0.5f) - r_wh / 2 + 1;
+        const int r_wx0 = (int)floorf(pcx * (float)r_W - 0.5f) - r_ww / 2 + 1;
+        if (lane < KL) {
+            const int ylo_ = rw_first(y0b, r_H, Hb), yhi_ = y1b >= Hb ? r_H : rw_first(y1b, r_H, Hb);
+            const int xlo_ = rw_first(x0b, r_W, Wb), xhi_ = x1b >= Wb ? r_W : rw_first(x1b, r_W, Wb);
+            r_ylo = ylo_;
+            r_xlo = xlo_;
+            r_w = max(xhi_ - xlo_, 1);
+            r_cnt = max(yhi_ - ylo_, 0) * max(xhi_ - xlo_, 0);
+            r_invw = 1.f / (float)r_w;
+        }
+        int cnt[KL], wy0[KL], wx0[KL], nq_total = 0;
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            cnt[l] = __builtin_amdgcn_readlane(r_cnt, l);
+            wy0[l] = __builtin_amdgcn_readlane(r_wy0, l);
+            wx0[l] = __builtin_amdgcn_readlane(r_wx0, l);
+            nq_total += cnt[l];
+        }
+        int my_wy0[NPASS], my_wx0[NPASS];
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            my_wy0[p] = __shfl(r_wy0, myl[p], 64);
+            my_wx0[p] = __shfl(r_wx0, myl[p], 64);
+        }
+
+        // ---- rounds: G queries at a time, 8 lanes each
+        const int nrounds = (nq_total + G - 1) / G;
+        auto slot_query = [&](int s) -> int {      // s-th query of the region (levels in order) or -1
+            const bool ok = s < nq_total;
+            int lq = 0;
+#pragma unroll
+            for (int l = 0; l < KL - 1; ++l)
+                if (lq == l && s >= cnt[l]) { s -= cnt[l]; lq = l + 1; }
+            const int yl = __shfl(r_ylo, lq, 64), xl = __shfl(r_xlo, lq, 64), w_ = __shfl(r_w, lq, 64);
+            const int st_ = __shfl(r_st, lq, 64), W_ = __shfl(r_W, lq, 64);
+            // s / w_ through the reciprocal: s < 2^15 and (s + 0.5) / w_ is at least 0.5 / w_ away from an integer
+            const int dy = (int)(((float)s + 0.5f) * __shfl(r_invw, lq, 64));
+            return ok ? st_ + (yl + dy) * W_ + xl + (s - dy * w_) : -1;
+        };
+        // raw sample data of a round: loaded one round ahead of its use
+        float rx[NPASS], ry[NPASS], ra[NPASS];
+        float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+        int q = slot_query(oc);
+        auto load_round = [&](int qq) {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int k = j8 + 8 * p;
+                rx[p] = ry[p] = ra[p] = 0.f;
+                if (qq >= 0 && k < KLP) {
+                    const int64_t nq = (int64_t)n * Lq + qq, row = nq * M + m;
+                    io.load_xy(row, nq, KLP, k, myl[p], P, myH[p], myW[p], rx[p], ry[p]);
+                    ra[p] = io.load_w(row, KLP, k);
+                }
+            }
+            if (GATHER && qq >= 0)
+                go = *reinterpret_cast<const float4 *>(gout + (((int64_t)n * Lq + qq) * M + m) * kD + 4 * j8);
+        };
+        load_round(q);
+
+        lap(0);                            // 0: region set-up (rectangles, round-0 loads issued)
+        // ---- stage the windows through registers: all loads of a thread first, then its stores
+        {
+            constexpr int RPS = NT / 8;                                   // window rows covered per step (8 lanes per row)
+            constexpr int kMaxSteps = (Wn::zrow + RPS - 1) / RPS + KL;
+            float4 sv[kMaxSteps];
+            if (DBG != 2) {
+                int nst = 0;
+#pragma unroll
+                for (int l = 0; l < KL; ++l) {
+                    const int ww_ = Wn::ww(l), rows_ = Wn::rows(l);
+                    int r = oc, wy = oc / ww_, wx = oc - wy * ww_;           // this thread's row inside level l's window
+#pragma unroll
+                    for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
+                        const int py = wy0[l] + wy, px = wx0[l] + wx;
+                        const bool ok = r < rows_ && (unsigned)py < (unsigned)Hs[l] && (unsigned)px < (unsigned)Ws[l];
+                        const unsigned goff = ok ? (unsigned)(sts[l] + py * Ws[l] + px) * row_bytes + lane_b : kOob;
+                        sv[nst++] = buf_ld4(vr, goff);
+                        r += RPS;
+                        wx += RPS % ww_;
+                        wy += RPS / ww_;
+                        if (wx >= ww_) { wx -= ww_; ++wy; }
+                    }
+                }
+            }
+            lap(1);                        // 1: staging loads issued
+            __syncthreads();               // every wave is done with the previous region's windows
+            lap(2);                        // 2: waiting for the other waves at the region boundary
+            if (DBG != 2) {
+                int ist = 0;
+#pragma unroll
+                for (int l = 0; l < KL; ++l) {
+                    const int rows_ = Wn::rows(l);
+                    int r = oc;
+#pragma unroll
+                    for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
+                        if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8 * 16) = sv[ist];
+                        ++ist;
+                        r += RPS;
+                    }
+                }
+            }
+            if (oc < Wn::zrows)
+                *reinterpret_cast<float4 *>(lds + kZ0 + oc * 128 + j8 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        lap(3);                            // 3: windows stored (incl. the wait for the staging loads)
+        __syncthreads();                   // the windows are complete
+        lap(4);                            // 4: waiting for the other waves' stores
+
+        for (int round = 0; round < nrounds; ++round) {
+            // ---- geometry of my samples -> records
+            float sx[NPASS], sy[NPASS], sa[NPASS];
+            const float4 mygo = go;
+            unsigned fbm = 0;                     // bit p: my sample of pass p is valid but leaves its window
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                sx[p] = rx[p];
+                sy[p] = ry[p];
+                sa[p] = ra[p];
+            }
+            if (IO::kSoftmax) {
+                // the softmax of the fused prologue over the row's L*P logits: they sit in NPASS registers of the octet's
+                // 8 lanes (row_softmax expects LP consecutive lanes), so reduce by hand
+                float mx = -__builtin_huge_valf();
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p)
+                    if (j8 + 8 * p < KLP) mx = fmaxf(mx, sa[p]);
+                mx = fmaxf(mx, dpp_mov<0xB1>(mx));
+                mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+                mx = fmaxf(mx, dpp_mov<0x141>(mx));
+                float sum = 0.f;
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) {
+                    sa[p] = (j8 + 8 * p < KLP) ? expf(sa[p] - mx) : 0.f;
+                    sum += sa[p];
+                }
+                sum = group8_sum(sum);
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) sa[p] = sa[p] / sum;
+            }
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int k = j8 + 8 * p;
+                const float Hf = (float)myH[p], Wf = (float)myW[p];
+                const float h = sub_rn(mul_rn(sy[p], Hf), 0.5f), w = sub_rn(mul_rn(sx[p], Wf), 0.5f);
+                const bool inside = q >= 0 && k < KLP && h > -1.f && w > -1.f && h < Hf && w < Wf;
+                const float h0f = floorf(h), w0f = floorf(w);
+                const float lh = sub_rn(h, h0f), lw = sub_rn(w, w0f);
+                const int wy = (int)h0f - my_wy0[p], wx = (int)w0f - my_wx0[p];
+                const bool inwin = inside && (unsigned)wy < (unsigned)my_wh1[p] && (unsigned)wx < (unsigned)my_ww1[p];
+                const bool fine = FG && myl[p] == 0;             // level 0 without a window: global corner offsets instead
+                if (inside && !inwin && !fine) fbm |= 1u << p;
+                const float a = sa[p], hh = 1.f - lh, hw = 1.f - lw;
+                // reading order: column sw first (sw = parity of the top-left row ^ octet class), see the header
+                const int rl = my_row0[p] + wy * my_ww[p] + wx;      // window row of the top-left corner
+                const int sw = (rl ^ cls) & 1;
+                // first = (top, column sw), partner = (top, column !sw); the bottom rows follow at + pitch (an immediate in
+                // the loop).  A sample that is not served from the window reads the zero rows (also at + its pitch).
+                const unsigned first = inwin ? (unsigned)(rl + sw) * 128u : kZ0 + (unsigned)cls * 128u;
+                const unsigned partner = inwin ? (unsigned)(rl + 1 - sw) * 128u : kZ0 + (unsigned)(1 - cls) * 128u;
+                if (fine && k < P) {
+                    // {4 corner byte offsets (kOob: outside the level / no sample), 4 weights}: the plain kernel's record
+                    const int h0 = (int)h0f, w0 = (int)w0f;
+                    const bool top = h0 >= 0, bot = h0 + 1 <= myH[p] - 1, lef = w0 >= 0, rig = w0 + 1 <= myW[p] - 1;
+                    const unsigned base = (unsigned)(myst[p] + h0 * myW[p] + w0) * row_bytes;      // may wrap for -1: unused then
+                    const unsigned wrow = (unsigned)myW[p] * row_bytes;
+                    *reinterpret_cast<uint4 *>(orec + kFineAt + k * 32) = make_uint4(
+                        inside && top && lef ? base : kOob, inside && top && rig ? base + row_bytes : kOob,
+                        inside && bot && lef ? base + wrow : kOob, inside && bot && rig ? base + wrow + row_bytes : kOob);
+                    *reinterpret_cast<float4 *>(orec + kFineAt + k * 32 + 16) = inside
+                        ? make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (k < KLP && !(FG && k < P)) {
+                    *reinterpret_cast<unsigned *>(orec + kOffAt + k * 4) = (first >> 4) | ((partner >> 4) << 16);
+                    if (!GATHER) {
+                        const float wl_t = inwin ? a * (hh * hw) : 0.f, wl_b = inwin ? a * (lh * hw) : 0.f;
+                        const float wr_t = inwin ? a * (hh * lw) : 0.f, wr_b = inwin ? a * (lh * lw) : 0.f;
+                        // weights in reading order: top sw, top !sw, bottom sw, bottom !sw
+                        *reinterpret_cast<float4 *>(orec + k * 16) = sw ? make_float4(wr_t, wl_t, wr_b, wl_b)
+                                                                        : make_float4(wl_t, wr_t, wl_b, wr_b);
+                    } else {
+                        // a NaN location must not leak through 0 * NaN: everything zero unless served from the window
+                        *reinterpret_cast<float4 *>(orec + k * 16) =
+                            make_float4(inwin ? lw : 0.f, inwin ? lh : 0.f, inwin ? a : 0.f, __int_as_float(sw));
+                    }
+                }
+            }
+            const int q_cur = q;
+            lap(5);                                // 5: geometry + record writes (incl. the wait for the round's raw data)
+            // ---- next round's raw data (its latency hides behind this round's compute)
+            q = slot_query((round + 1) * G + oc);
+            if (round + 1 < nrounds) load_round(q);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my wave's records are written
+
+            // out-of-window samples of this wave: per octet a mask over (pass, lane)
+            unsigned gmask = 0, allmask = 0;
+            int n_out = 0;
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const unsigned long long bal = __ballot((fbm >> p) & 1u);
+                const unsigned long long balv = __ballot(q_cur >= 0 && j8 + 8 * p < KLP && !(FG && j8 + 8 * p < P));
+                gmask |= ((unsigned)(bal >> (lane & 56)) & 0xffu) << (8 * p);
+                allmask |= ((unsigned)(balv >> (lane & 56)) & 0xffu) << (8 * p);
+                n_out += __popcll(bal);
+            }
+            const bool plain_round = n_out * 3 > 64 * NPASS;
+            if (plain_round) gmask = allmask;      // every sample of the round takes the global path below
+
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float m_a[NPASS], m_x[NPASS], m_y[NPASS];      // GATHER: d/d attn, d/d x, d/d y of my samples
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) m_a[p] = m_x[p] = m_y[p] = 0.f;
+            // one sample of the gather: partial dots over my 4 channels with the four corners -> the three small gradients,
+            // summed over the 8 lanes of the octet; the lane that owns sample k keeps them.  V1..V4 = top-left, top-right,
+            // bottom-left, bottom-right.
+#define RW_DOT4(V_) (mygo.x * (V_).x + mygo.y * (V_).y + mygo.z * (V_).z + mygo.w * (V_).w)
+#define RW_GATHER_STEP(P_, J_, V1_, V2_, V3_, V4_, LW_, LH_, A_)                                            \
+            do {                                                                                               \
+                const float d1_ = RW_DOT4(V1_), d2_ = RW_DOT4(V2_), d3_ = RW_DOT4(V3_), d4_ = RW_DOT4(V4_);    \
+                const float hh_ = 1.f - (LH_), hw_ = 1.f - (LW_);                                              \
+                const float t_ = hw_ * d1_ + (LW_) * d2_, b_ = hw_ * d3_ + (LW_) * d4_;                        \
+                float pa_ = hh_ * t_ + (LH_) * b_;                                                             \
+                float px_ = (A_) * (hh_ * (d2_ - d1_) + (LH_) * (d4_ - d3_));                                  \
+                float py_ = (A_) * (b_ - t_);                                                                  \
+                pa_ = group8_sum(pa_);                                                                         \
+                px_ = group8_sum(px_);                                                                         \
+                py_ = group8_sum(py_);                                                                         \
+                const bool own_ = j8 == (J_);                                                                  \
+                m_a[P_] = own_ ? pa_ : m_a[P_];                                                                \
+                m_x[P_] = own_ ? px_ : m_x[P_];                                                                \
+                m_y[P_] = own_ ? py_ : m_y[P_];                                                                \
+            } while (0)
+            // publish sample k's global corner offsets + geometry in slot `sl` of the octet (owner lane only)
+            auto publish = [&](bool act, int k, int sl) {
+                if (act && j8 == (k & 7)) {
+                    const int p = k >> 3;
+                    unsigned off[4];
+                    float lw, lh;
+                    float px_ = sx[0], py_ = sy[0], a_ = sa[0];
+                    int H_ = myH[0], W_ = myW[0], st_ = myst[0];
+#pragma unroll
+                    for (int pp = 1; pp < NPASS; ++pp)
+                        if (p == pp) { px_ = sx[pp]; py_ = sy[pp]; a_ = sa[pp]; H_ = myH[pp]; W_ = myW[pp]; st_ = myst[pp]; }
+                    sample_setup_oob(px_, py_, H_, W_, st_, row_bytes, off, lw, lh);
+                    *reinterpret_cast<uint4 *>(orec + kSlotAt + 32 * sl) = make_uint4(off[0], off[1], off[2], off[3]);
+                    *reinterpret_cast<float4 *>(orec + kSlotAt + 32 * sl + 16) = make_float4(lw, lh, a_, 0.f);
+                }
+            };
+            // consume a published sample: accumulate (forward) / take its three gradients (gather)
+            auto consume_fwd = [&](const float4 &g, const float4 &v1, const float4 &v2, const float4 &v3, const float4 &v4) {
+                const float hh = 1.f - g.y, hw = 1.f - g.x;
+                const float w1 = g.z * (hh * hw), w2 = g.z * (hh * g.x), w3 = g.z * (g.y * hw), w4 = g.z * (g.y * g.x);
+                acc.x = fmaf(w4, v4.x, fmaf(w3, v3.x, fmaf(w2, v2.x, fmaf(w1, v1.x, acc.x))));
+                acc.y = fmaf(w4, v4.y, fmaf(w3, v3.y, fmaf(w2, v2.y, fmaf(w1, v1.y, acc.y))));
+                acc.z = fmaf(w4, v4.z, fmaf(w3, v3.z, fmaf(w2, v2.z, fmaf(w1, v1.z, acc.z))));
+                acc.w = fmaf(w4, v4.w, fmaf(w3, v3.w, fmaf(w2, v2.w, fmaf(w1, v1.w, acc.w))));
+            };
+            // ---- the first two out-of-window samples of every octet: corner loads issued NOW, consumed after the LDS loop
+            //      (their latency hides behind it); further ones take the loop at the end
+            constexpr int kPre = TUNE % 10, kSB = TUNE / 10;
+            bool pact[kPre > 0 ? kPre : 1];
+            int pk[kPre > 0 ? kPre : 1];
+            float4 pg[kPre > 0 ? kPre : 1], pv[kPre > 0 ? kPre : 1][4];
+            const bool any_out = kPre > 0 && !plain_round && __any(gmask != 0);
+            if (any_out) {
+#pragma unroll
+                for (int i = 0; i < kPre; ++i) {
+                    pact[i] = gmask != 0;
+                    pk[i] = pact[i] ? __ffs((int)gmask) - 1 : 0;
+                    gmask &= gmask - 1;
+                    publish(pact[i], pk[i], i);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < kPre; ++i) {
+                    const uint4 o = *reinterpret_cast<const uint4 *>(orec + kSlotAt + 32 * i);
+                    pg[i] = *reinterpret_cast<const float4 *>(orec + kSlotAt + 32 * i + 16);
+                    // an octet without such a sample reads out of range: zeros, no memory access
+                    pv[i][0] = buf_ld4(vr, (pact[i] ? o.x : kOob) + lane_b);
+                    pv[i][1] = buf_ld4(vr, (pact[i] ? o.y : kOob) + lane_b);
+                    pv[i][2] = buf_ld4(vr, (pact[i] ? o.z : kOob) + lane_b);
+                    pv[i][3] = buf_ld4(vr, (pact[i] ? o.w : kOob) + lane_b);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slots read before anything rewrites them
+            }
+            // ---- level 0 without a window: its 4 x 4 corner rows come through the vector-memory path, issued now and
+            //      consumed after the LDS loop (the two pipes work side by side)
+            float4 fv[FG ? 2 : 1][4], fw[FG ? 2 : 1];           // two samples in flight at a time (registers: 2 x 20)
+            auto fine_issue = [&](int k0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint4 o = *reinterpret_cast<const uint4 *>(orec + kFineAt + (k0 + i) * 32);
+                    fw[i] = *reinterpret_cast<const float4 *>(orec + kFineAt + (k0 + i) * 32 + 16);
+                    fv[i][0] = buf_ld4(vr, o.x + lane_b);
+                    fv[i][1] = buf_ld4(vr, o.y + lane_b);
+                    fv[i][2] = buf_ld4(vr, o.z + lane_b);
+                    fv[i][3] = buf_ld4(vr, o.w + lane_b);
+                }
+            };
+            auto fine_consume = [&]() {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc.x = fmaf(fw[i].w, fv[i][3].x, fmaf(fw[i].z, fv[i][2].x, fmaf(fw[i].y, fv[i][1].x, fmaf(fw[i].x, fv[i][0].x, acc.x))));
+                    acc.y = fmaf(fw[i].w, fv[i][3].y, fmaf(fw[i].z, fv[i][2].y, fmaf(fw[i].y, fv[i][1].y, fmaf(fw[i].x, fv[i][0].y, acc.y))));
+                    acc.z = fmaf(fw[i].w, fv[i][3].z, fmaf(fw[i].z, fv[i][2].z, fmaf(fw[i].y, fv[i][1].z, fmaf(fw[i].x, fv[i][0].z, acc.z))));
+                    acc.w = fmaf(fw[i].w, fv[i][3].w, fmaf(fw[i].z, fv[i][2].w, fmaf(fw[i].y, fv[i][1].w, fmaf(fw[i].x, fv[i][0].w, acc.w))));
+                }
+            };
+            if (FG) fine_issue(0);
+            lap(6);                                // 6: next round's loads issued, masks, pre-issued corner loads
+            if (!plain_round && DBG != 3) {
+                // ---- the common case: every corner from LDS, in the order (top, sw), (top, !sw), (bottom, sw), (bottom, !sw)
+#pragma unroll
+                for (int k = FG ? P : 0; k < KLP; ++k) {
+                    const int pitch = Wn::ww(k / P) * 128;
+                    const float4 r = *reinterpret_cast<const float4 *>(orec + k * 16);
+                    const unsigned o = *reinterpret_cast<const unsigned *>(orec + kOffAt + k * 4);
+                    const char *a0 = wbase + ((o & 0xffffu) << 4), *a1 = wbase + ((o >> 16) << 4);
+                    const float4 f1 = *reinterpret_cast<const float4 *>(a0);
+                    const float4 f2 = *reinterpret_cast<const float4 *>(a1);
+                    const float4 f3 = *reinterpret_cast<const float4 *>(a0 + pitch);
+                    const float4 f4 = *reinterpret_cast<const float4 *>(a1 + pitch);
+                    if (!GATHER) {
+                        acc.x = fmaf(r.w, f4.x, fmaf(r.z, f3.x, fmaf(r.y, f2.x, fmaf(r.x, f1.x, acc.x))));
+                        acc.y = fmaf(r.w, f4.y, fmaf(r.z, f3.y, fmaf(r.y, f2.y, fmaf(r.x, f1.y, acc.y))));
+                        acc.z = fmaf(r.w, f4.z, fmaf(r.z, f3.z, fmaf(r.y, f2.z, fmaf(r.x, f1.z, acc.z))));
+                        acc.w = fmaf(r.w, f4.w, fmaf(r.z, f3.w, fmaf(r.y, f2.w, fmaf(r.x, f1.w, acc.w))));
+                        if (k % kSB == kSB - 1) __builtin_amdgcn_sched_barrier(0);      // bounds the registers of the unrolled loop
+                        if (FG && k == (P + KLP) / 2 - 1) { fine_consume(); fine_issue(2); __builtin_amdgcn_sched_barrier(0); }
+                    } else {
+                        const bool sw = __float_as_int(r.w) != 0;
+                        const float4 vtl = sw ? f2 : f1, vtr = sw ? f1 : f2, vbl = sw ? f4 : f3, vbr = sw ? f3 : f4;
+                        RW_GATHER_STEP(k >> 3, k & 7, vtl, vtr, vbl, vbr, r.x, r.y, r.z);
+                        // keep the scheduler from hoisting the whole unrolled loop's LDS reads (256 VGPRs and spills otherwise)
+                        if (k % (kSB / 2 > 0 ? kSB / 2 : 1) == (kSB / 2 > 0 ? kSB / 2 : 1) - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (FG) {
+                if (plain_round || DBG == 3) { fine_consume(); fine_issue(2); }      // the LDS loop (and its mid-point) was skipped
+                fine_consume();
+            }
+            lap(7);                                // 7: compute loop (LDS)
+            if (any_out) {
+#pragma unroll
+                for (int i = 0; i < kPre; ++i) {
+                    if (!GATHER) {
+                        if (pact[i]) consume_fwd(pg[i], pv[i][0], pv[i][1], pv[i][2], pv[i][3]);
+                    } else if (pact[i]) {
+#pragma unroll
+                        for (int pp = 0; pp < NPASS; ++pp)
+                            if ((pk[i] >> 3) == pp)
+                                RW_GATHER_STEP(pp, pk[i] & 7, pv[i][0], pv[i][1], pv[i][2], pv[i][3], pg[i].x, pg[i].y, pg[i].z);
+                    }
+                }
+            }
+            // ---- what is left (all samples in a plain round): per trip every octet takes its next such sample, the owner
+            //      lane publishes its corner offsets and geometry, the octet loads the four corners
+            while (__any(gmask != 0)) {
+                const bool act = gmask != 0;
+                const int k = act ? __ffs((int)gmask) - 1 : 0;
+                gmask &= gmask - 1;
+                publish(act, k, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (act) {
+                    const uint4 o = *reinterpret_cast<const uint4 *>(orec + kSlotAt);
+                    const float4 g = *reinterpret_cast<const float4 *>(orec + kSlotAt + 16);
+                    const float4 v1 = buf_ld4(vr, o.x + lane_b), v2 = buf_ld4(vr, o.y + lane_b);
+                    const float4 v3 = buf_ld4(vr, o.z + lane_b), v4 = buf_ld4(vr, o.w + lane_b);
+                    if (!GATHER) {
+                        consume_fwd(g, v1, v2, v3, v4);
+                    } else {
+                        // k is a runtime value here: one instantiation per pass
+#pragma unroll
+                        for (int pp = 0; pp < NPASS; ++pp)
+                            if ((k >> 3) == pp) RW_GATHER_STEP(pp, k & 7, v1, v2, v3, v4, g.x, g.y, g.z);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slot read before the next trip rewrites it
+            }
+            lap(8);                                // 8: out-of-window samples
+            if (DBG == 1 && tid == 0) atomicAdd(&g_dest_dbg[10], 1ull);
+            // ---- results
+            if (!GATHER) {
+                if (q_cur >= 0)
+                    *reinterpret_cast<float4 *>(out + (((int64_t)n * Lq + q_cur) * M + m) * kD + 4 * j8) = acc;
+            } else {
+                float dot = 0.f;                   // fused epilogue: sum_k a_k g_k over the row
+                if (IO::kSoftmax) {
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p) dot += (j8 + 8 * p < KLP) ? sa[p] * m_a[p] : 0.f;
+                    dot = group8_sum(dot);
+                }
+                if (q_cur >= 0) {
+                    const int64_t nq_c = (int64_t)n * Lq + q_cur, row_c = nq_c * M + m;
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p) {
+                        const int k = j8 + 8 * p;
+                        if (k < KLP) {
+                            const float4 res = make_float4(m_a[p], m_x[p] * (float)myW[p], m_y[p] * (float)myH[p], sa[p]);
+                            io.store_with_dot(row_c, nq_c, KLP, k, myl[p], P, myH[p], myW[p], res, dot);
+                        }
+                    }
+                }
+            }
+#undef RW_GATHER_STEP
+#undef RW_DOT4
+            lap(9);                                // 9: results
+        }
+        if (DBG == 1 && tid == 0) atomicAdd(&g_dest_dbg[11], 1ull);
+    }
+}

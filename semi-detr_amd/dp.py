@@ -282,7 +282,15 @@ class FlatDDP(torch.nn.Module):
             self._next += 1
 
     def _finalize(self):
-        """End of backward: reduce what is left (unused parameters), wait, sums -> means."""
+        """End of backward: reduce what is left (unused parameters), wait, sums -> means.
+
+        Parameters that did not fire in THIS backward are handled like torch DDP does:
+          * a gradient that is already there -- accumulated by an earlier ``no_sync()`` pass or by a multi-backward
+            scheme such as mmcv's GradientCumulativeOptimizerHook -- is reduced AS IT STANDS, never zeroed;
+          * a parameter whose ``.grad`` is ``None`` contributes zeros to the collective and keeps ``None`` afterwards
+            unless some other rank used it (a used-bitmap is all-reduced next to the buckets, as torch DDP does), so
+            an optimizer with weight decay / momentum does not touch globally unused parameters.
+        """
         try:
             unused = [i for i, f in enumerate(self._fired) if not f]
             if unused and not self.find_unused_parameters:
@@ -290,15 +298,32 @@ class FlatDDP(torch.nn.Module):
                     "FlatDDP: %d parameters did not receive a gradient in this backward pass. Pass "
                     "find_unused_parameters=True (as cfg.find_unused_parameters does at detr_ssod/apis/train.py:85) "
                     "if that is expected." % len(unused))
-            for i in unused:                         # contributes zero to the mean, like torch DDP
-                if self._views[i] is not self.params[i].grad:
-                    self.params[i].grad = self._views[i]
-                self._views[i].zero_()
+            were_none, bitmap, bm_work = [], None, None
+            for i in unused:
+                p, v = self.params[i], self._views[i]
+                if p.grad is None:
+                    v.zero_()                       # stale arena content must not enter the mean
+                    were_none.append(i)
+                elif p.grad is not v and p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)                  # accumulated outside the arena: bring it home, keep its content
+                    p.grad = v
             self._launch_ready(force=True)
+            if self.find_unused_parameters:          # every rank takes part, whether or not IT has unused parameters;
+                # issued AFTER the last bucket on every rank: collectives must be queued in the same order everywhere
+                bitmap = torch.tensor([1 if f else 0 for f in self._fired], dtype=torch.int32,
+                                      device=self.arena.flat.device)
+                bm_work = dist.all_reduce(bitmap, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             for w in self._pending:
                 w.wait()
             if not self._avg:
                 self.arena.flat.div_(self.world)
+            if bm_work is not None:
+                bm_work.wait()
+                if were_none:
+                    used = bitmap.tolist()
+                    for i in were_none:
+                        if used[i] > 0:              # some rank produced a gradient: the mean is this rank's too
+                            self.params[i].grad = self._views[i]
         finally:
             self._reset()
 

@@ -198,6 +198,35 @@ def _ddp_worker(rank, world, port, q):
         gs = [torch.zeros_like(g) for _ in range(world)]
         dist.all_gather(gs, g)
         assert torch.equal(gs[0], gs[1]) and gs[0].abs().sum() > 0    # mean of (rank 0's gradient, zeros)
+        # --- a parameter that is unused in the synchronising backward keeps what an earlier no_sync() pass
+        #     accumulated (reduced as it stands, exactly like torch DDP), and a globally unused parameter whose grad is
+        #     None stays None (so weight decay / momentum never touch it)
+        flat4 = dp.FlatDDP(copy.deepcopy(base), find_unused_parameters=True, bucket_bytes=8192)
+        ref4 = torch.nn.parallel.DistributedDataParallel(copy.deepcopy(flat4.module), broadcast_buffers=False,
+                                                         find_unused_parameters=True, bucket_cap_mb=0.008)
+        for mdl in (flat4, ref4):
+            for prm in mdl.parameters():
+                prm.grad = None
+            with mdl.no_sync():
+                mdl(xs[1][rank], use_extra=True).backward()        # `extra` accumulates locally
+            mdl(xs[2][rank], use_extra=False).backward()           # ... and is unused in the synchronising pass
+        assert flat4.module.extra.weight.grad.abs().sum() > 0, "accumulated gradient was discarded"
+        for pa, pb in zip(flat4.module.parameters(), ref4.module.parameters()):
+            if pa.requires_grad:
+                assert torch.allclose(pa.grad, pb.grad, rtol=1e-6, atol=1e-7), "accumulate-then-sync must equal torch DDP"
+        for prm in flat4.parameters():
+            prm.grad = None                                          # zero_grad(set_to_none=True)
+        flat4(xs[0][rank], use_extra=False).backward()               # `extra` unused on EVERY rank
+        assert flat4.module.extra.weight.grad is None and flat4.module.extra.bias.grad is None
+        assert flat4.module.fc2.weight.grad is not None
+        for prm in flat4.parameters():
+            prm.grad = None
+        flat4(xs[0][rank], use_extra=(rank == 1)).backward()         # used on rank 1 only: every rank gets the mean
+        g4 = flat4.module.extra.weight.grad
+        assert g4 is not None
+        gs4 = [torch.zeros_like(g4) for _ in range(world)]
+        dist.all_gather(gs4, g4)
+        assert torch.equal(gs4[0], gs4[1]) and gs4[0].abs().sum() > 0
         # --- no_sync: local accumulation, no communication
         flat3.zero_grad()
         with flat3.no_sync():
