@@ -313,14 +313,20 @@ def hbm_stream_peak(dev):
     the denominator of `frac_hbm_measured` (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy)."""
     import ctypes
     import semi_detr_amd as sda
-    lib = sda._lib.lib()
+    # the streaming probe is a measurement aid, not part of the product: it lives in the experiments build of the library
+    # (include/semidetr_hip_experiments.h), loaded here ONLY for this probe -- every timed launch of the bench goes through
+    # the product library
+    probe = ctypes.CDLL(os.path.join(ROOT, "semi-detr_amd", "csrc", "libsemidetr_hip_exp.so"))
+    probe.semidetr_stream_copy_f32.restype = ctypes.c_int
+    probe.semidetr_stream_copy_f32.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_int]
     a = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
     b = torch.empty_like(a)
     stream = sda._lib.current_stream_ptr
 
     def own(nt):
-        sda._lib.check(lib.semidetr_stream_copy_f32(stream(), ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()),
-                                                    a.numel(), nt), "stream_copy")
+        rc = probe.semidetr_stream_copy_f32(stream(), ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), a.numel(), nt)
+        if rc != 0:
+            raise RuntimeError(f"stream_copy failed (code {rc})")
 
     res = {}
     bytes_per_call = {"ema_triad_2r1w": 3 * a.numel() * 4, "own_float4_read_only": a.numel() * 4}

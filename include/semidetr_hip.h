@@ -25,7 +25,7 @@ extern "C" {
 #define SEMIDETR_E_TOOLARGE (-2)    /* an index would overflow the 32-bit arithmetic used on device  */
 #define SEMIDETR_E_NODEVICE (-3)    /* no HIP device available                                        */
 
-#define SEMIDETR_ABI_VERSION 3
+#define SEMIDETR_ABI_VERSION 4
 
 int semidetr_abi_version(void);
 const char *semidetr_last_error(void);
@@ -58,9 +58,10 @@ const char *semidetr_last_error(void);
  * spatial_size).  The level table lives in device memory, so the library cannot verify this without a
  * host synchronisation: the CALLER vouches for it (the Python / pybind layer checks it once per
  * spatial_shapes tensor).  With the flag the forward / gather kernels take 2-D pixel patches and
- * grad_value is produced by the destination-owned kernel; without it every query set takes the strip
+ * grad_value is produced by the region-owned scatter kernel; without it every query set takes the strip
  * kernels, which make no assumption (the reference op has no such coupling).  Results are identical
- * either way (up to fp32 summation order); the flag only selects faster kernels.
+ * either way (up to fp32 summation order); the flag only selects faster kernels.  With the flag the backward clears
+ * grad_value inside its first kernel; grad_value of the encoder path is produced by the region-owned scatter.
  * ------------------------------------------------------------------------------------------- */
 #define SEMIDETR_MSDA_QUERIES_ARE_PIXELS 1
 int semidetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
@@ -117,20 +118,6 @@ int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const 
 /* Names of the device kernels the LAST semidetr_msda_* call of the calling thread launched ("+"-separated, as the
  * profiler prints their base names), so that a benchmark reports what actually ran instead of a hand-kept table. */
 const char *semidetr_msda_last_kernels(void);
-
-/* Tuning aid: per-phase cycle counters of the instrumented destination-owned kernel (set_variant(.., 73)); host
- * array of 16 values; reset != 0 zeroes the device counters after reading. */
-int semidetr_debug_counters(unsigned long long *out16, int reset);
-
-/* Measurement aid: float4 streaming pass over `numel` fp32 values (multiple of 4, 16-byte aligned); mode 0 = copy,
- * 1 = copy with nontemporal accesses, 2 = read only.  The best copy rate of the box is what bench.py quotes
- * `frac_hbm_measured` against. */
-int semidetr_stream_copy_f32(void *stream, float *dst, const float *src, int64_t numel, int mode);
-
-/* TEST / TUNING ONLY -- not part of the re-entrant contract above: forces a kernel variant of the f32 /
- * channels==32 fast path for every later call of the process (0 = automatic choice; codes in DESIGN.md 2.3b).
- * Process-wide and not thread-safe; nothing in semi-detr_amd/ calls it, tests and tools/ reset it to (0, 0). */
-void semidetr_msda_set_variant(int fwd_variant, int bwd_variant);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matcher: cost matrix + linear sum assignment + assignment scatter, batched and

@@ -19,9 +19,14 @@ What is imported from the reference (by file path, with stub registries for the 
   * detr_ssod/models/utils/bbox_utils.py (Transform2D.transform_bboxes)
   * detr_od/core/bbox/assigners/o2m_assigner.py (O2MAssigner) + o2m_assign_result.py
   * detr_od/models/losses/task_aligned_focal_loss.py (task_aigned_focal_loss) + mmdet losses/utils.py
-The assignment itself comes from scipy.optimize.linear_sum_assignment (scipy 1.15.3), exactly as
-hungarian_assigner.py:136 calls it.  MeanTeacher / pseudo-label code needs mmcv to import, so those
-fixtures restate mean_teacher.py:46-64 and dino_detr_ssod.py:918-939 with the same torch calls.
+  * thirdparty/mmdetection/mmdet/core/bbox/assigners/hungarian_assigner.py (HungarianAssigner.assign itself, with the real
+    assign_result.py / base_assigner.py; stubs only for the registry, NiceRepr and the debug logger) -- assigned_gt_inds /
+    labels in cost.npz are its outputs, incl. the no-ground-truth early-out (:108-114)
+  * detr_ssod/utils/hooks/mean_teacher.py (MeanTeacher, driven through before_run / before_train_iter / after_train_iter
+    with a fake runner; stubs: mmcv.parallel.is_module_wrapper, mmcv.runner.hooks.HOOKS / Hook, ..logger.log_every_n)
+The assignment inside HungarianAssigner.assign comes from scipy.optimize.linear_sum_assignment (scipy 1.15.3, a third-party
+dependency the reference does not vendor), exactly as hungarian_assigner.py:136 calls it.  The pseudo-label filter needs all
+of mmdet to import, so that fixture restates dino_detr_ssod.py:918-939 with the same torch calls.
 """
 import importlib.util
 import os
@@ -309,8 +314,43 @@ def ref_cost(mc, tr, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_w, img_h):
     return c1, c2, c3, c1 + c2 + c3
 
 
+def load_hungarian_assigner(mc):
+    """The reference's HungarianAssigner class itself (hungarian_assigner.py:15-188)."""
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        m.__path__ = getattr(m, "__path__", [])
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda c: c
+
+    bb = REF + "/thirdparty/mmdetection/mmdet/core/bbox"
+    mod("mmdet.core.bbox.builder", BBOX_ASSIGNERS=_Reg())
+    # build_match_cost: what mmcv's build_from_cfg does for these three classes -- type -> class, rest -> kwargs
+    mod("mmdet.core.bbox.match_costs",
+        build_match_cost=lambda cfg: getattr(mc, cfg["type"])(**{k: v for k, v in cfg.items() if k != "type"}))
+    mod("mmdet.utils")
+    mod("mmdet.utils.util_mixins", NiceRepr=object)
+    sys.modules["mmdet.utils"].util_mixins = sys.modules["mmdet.utils.util_mixins"]
+    mod("mmdet.core.bbox.assigners")
+    mod("mmdet.core.bbox.assigners.logger", log_image_with_boxes=lambda *a, **k: None)      # debug=True only
+    _load("mmdet.core.bbox.assigners.assign_result", bb + "/assigners/assign_result.py", "mmdet.core.bbox.assigners")
+    _load("mmdet.core.bbox.assigners.base_assigner", bb + "/assigners/base_assigner.py", "mmdet.core.bbox.assigners")
+    ha = _load("mmdet.core.bbox.assigners.hungarian_assigner", bb + "/assigners/hungarian_assigner.py",
+               "mmdet.core.bbox.assigners")
+    # the DINO config's assigner (configs/dino_detr/dino_detr_r50_8x2_12e_coco.py:41-44)
+    return ha.HungarianAssigner(cls_cost=dict(type="FocalLossCost", weight=2.0),
+                                reg_cost=dict(type="BBoxL1Cost", weight=5.0, box_format="xywh"),
+                                iou_cost=dict(type="IoUCost", iou_mode="giou", weight=2.0))
+
+
 def gen_cost(mc, tr):
     d = {}
+    ref_assigner = load_hungarian_assigner(mc)
     # the docstring known answer (match_cost.py:156-162)
     iou = mc.IoUCost()(torch.FloatTensor([[1, 1, 2, 2], [2, 2, 3, 4]]),
                        torch.FloatTensor([[0, 0, 2, 4], [1, 2, 3, 4]]))
@@ -340,20 +380,21 @@ def gen_cost(mc, tr):
         d[f"{n}.bbox_pred"], d[f"{n}.cls_pred"] = bbox_pred.numpy(), cls_pred.numpy()
         d[f"{n}.gt_bboxes"], d[f"{n}.gt_labels"] = gt.numpy(), labels.numpy()
         d[f"{n}.img_wh"] = np.asarray([img_w, img_h], np.float32)
-        gi = np.full(Q, -1, np.int64)
-        lab = np.full(Q, -1, np.int64)
+        # the assignment: HungarianAssigner.assign ITSELF (incl. the no-ground-truth early-out, :108-114)
+        res = ref_assigner.assign(bbox_pred, cls_pred, gt, labels, dict(img_shape=(img_h, img_w, 3)))
+        gi, lab = res.gt_inds.numpy().astype(np.int64), res.labels.numpy().astype(np.int64)
         if G == 0:
-            gi[:] = 0           # hungarian_assigner.py:108-114
             rows = cols = np.zeros(0, np.int64)
         else:
+            # the cost terms (same calls as assign :115-129) and scipy's row / column lists, kept for the per-term tests
             c1, c2, c3, c = ref_cost(mc, tr, bbox_pred, cls_pred, gt, labels, img_w, img_h)
             if Q * G <= 900 * 7:
                 d[f"{n}.cost_cls"], d[f"{n}.cost_reg"], d[f"{n}.cost_iou"] = c1.numpy(), c2.numpy(), c3.numpy()
             d[f"{n}.cost"] = c.numpy()
             rows, cols = linear_sum_assignment(c)
-            gi[:] = 0
-            gi[rows] = cols + 1
-            lab[rows] = labels.numpy()[cols]
+            chk = np.zeros(Q, np.int64)
+            chk[rows] = cols + 1
+            assert np.array_equal(chk, gi), "reference assign() and its own cost + scipy disagree"
         d[f"{n}.rows"], d[f"{n}.cols"] = rows.astype(np.int64), cols.astype(np.int64)
         d[f"{n}.assigned_gt_inds"], d[f"{n}.assigned_labels"] = gi, lab
     d["names"] = np.asarray(names)
@@ -396,24 +437,119 @@ def gen_lsap():
     np.savez_compressed(os.path.join(OUT, "lsap.npz"), **d)
 
 
+def load_mean_teacher():
+    """The reference's MeanTeacher hook class itself (detr_ssod/utils/hooks/mean_teacher.py:7-64)."""
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        m.__path__ = getattr(m, "__path__", [])
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Reg:
+        def register_module(self, *a, **k):
+            return lambda c: c
+
+    mod("mmcv")
+    mod("mmcv.parallel", is_module_wrapper=lambda m: hasattr(m, "module") and not hasattr(m, "teacher"))
+    mod("mmcv.runner")
+    mod("mmcv.runner.hooks", HOOKS=_Reg(), Hook=object)
+    mod("refssod")
+    mod("refssod.utils")
+    mod("refssod.utils.logger", log_every_n=lambda *a, **k: None)
+    mod("refssod.utils.hooks")
+    return _load("refssod.utils.hooks.mean_teacher", REF + "/detr_ssod/utils/hooks/mean_teacher.py",
+                 "refssod.utils.hooks").MeanTeacher
+
+
+class _FakeRunner:
+    """What MeanTeacher touches of an mmcv runner: .model, .iter, .log_buffer.output."""
+
+    def __init__(self, model):
+        self.model, self.iter = model, 0
+        self.log_buffer = types.SimpleNamespace(output={})
+
+
+def _ts_model(shapes, gen):
+    def net():
+        m = torch.nn.Module()
+        for i, shp in enumerate(shapes):
+            m.register_parameter(f"p{i}", torch.nn.Parameter(torch.randn(*shp, generator=gen)))
+        m.p0.requires_grad_(False)                      # frozen parameters are updated too (named_parameters(), :60-64)
+        m.register_buffer("buf", torch.randn(5, generator=gen))      # buffers are not
+        return m
+    model = torch.nn.Module()
+    model.teacher, model.student = net(), net()
+    return model
+
+
 def gen_ema():
-    """mean_teacher.py:46-48 (momentum schedule) and :60-64 (in-place update), via torch CPU."""
+    """Every number comes out of the reference's own MeanTeacher: the momentum schedule from before_train_iter's log entry
+    (:46-49), the update arithmetic from momentum_update (:60-64), the decay from after_train_iter (:52-58), the initial clone
+    from before_run (:26-35)."""
+    MT = load_mean_teacher()
     d = {}
     steps = np.asarray([0, 1, 2, 3, 4, 5, 99, 100, 998, 999, 1000, 5000], np.int64)
-    for wu in (0, 100):
-        d[f"sched_wu{wu}"] = np.asarray(
-            [min(0.999, 1 - (1 + wu) / (int(s) + 1 + wu)) for s in steps], np.float64)
-    d["sched_steps"] = steps
     g = torch.Generator().manual_seed(11)
+    for wu in (0, 100):
+        hook, runner = MT(momentum=0.999, interval=1, warm_up=wu), _FakeRunner(_ts_model([(2,)], g))
+        sched = []
+        for st in steps:
+            runner.iter = int(st)
+            hook.before_train_iter(runner)
+            sched.append(runner.log_buffer.output["ema_momentum"])
+        d[f"sched_wu{wu}"] = np.asarray(sched, np.float64)
+    d["sched_steps"] = steps
     shapes = [(16, 3, 7, 7), (64,), (48, 48), (1,), (17, 5), (100, 33)]
     for mi, mom in enumerate((0.0, 0.5, 0.999, 0.9996)):
-        for si, shp in enumerate(shapes):
-            t = torch.randn(*shp, generator=g)
-            s = torch.randn(*shp, generator=g)
-            d[f"m{mi}.t{si}.teacher"], d[f"m{mi}.t{si}.student"] = t.numpy().copy(), s.numpy().copy()
-            t.mul_(mom).add_(s, alpha=1 - mom)
-            d[f"m{mi}.t{si}.out"] = t.numpy()
+        model = _ts_model(shapes, g)
+        for si in range(len(shapes)):
+            d[f"m{mi}.t{si}.teacher"] = getattr(model.teacher, f"p{si}").detach().numpy().copy()
+            d[f"m{mi}.t{si}.student"] = getattr(model.student, f"p{si}").detach().numpy().copy()
+        MT().momentum_update(model, mom)
+        for si in range(len(shapes)):
+            d[f"m{mi}.t{si}.out"] = getattr(model.teacher, f"p{si}").detach().numpy().copy()
         d[f"m{mi}.momentum"] = np.float64(mom)
+    # whole hook sequences: before_run, then per iteration before_train_iter -> (the optimizer moves the student) ->
+    # after_train_iter; teacher snapshots + logged momenta.  The student's motion is a fixed, seeded perturbation.
+    seq_cfgs = {"plain": dict(momentum=0.999, interval=1, warm_up=0),
+                "warm100_int2": dict(momentum=0.9996, interval=2, warm_up=100),
+                "decay": dict(momentum=0.99, interval=1, warm_up=0, decay_intervals=[3, 6], decay_factor=0.1),
+                "wrapped": dict(momentum=0.999, interval=1, warm_up=2)}
+    seq_shapes = [(8, 3), (5,), (4, 4, 2)]
+    d["seq.names"] = np.asarray(sorted(seq_cfgs))
+    d["seq.iters"] = np.int64(9)
+    for name in sorted(seq_cfgs):
+        cfg = seq_cfgs[name]
+        gg = torch.Generator().manual_seed(500 + len(name))
+        model = _ts_model(seq_shapes, gg)
+        for si in range(len(seq_shapes)):
+            d[f"seq.{name}.teacher0.{si}"] = getattr(model.teacher, f"p{si}").detach().numpy().copy()
+            d[f"seq.{name}.student0.{si}"] = getattr(model.student, f"p{si}").detach().numpy().copy()
+        d[f"seq.{name}.buf0"] = model.teacher.buf.numpy().copy()
+        wrapped = types.SimpleNamespace(module=model) if name == "wrapped" else model      # is_module_wrapper path (:27-28)
+        hook, runner = MT(**cfg), _FakeRunner(wrapped)
+        hook.before_run(runner)
+        moms, hook_moms = [], []
+        for it in range(9):
+            runner.iter = it
+            runner.log_buffer.output.pop("ema_momentum", None)
+            hook.before_train_iter(runner)
+            moms.append(runner.log_buffer.output.get("ema_momentum", np.nan))      # nan: skipped by `interval`
+            with torch.no_grad():
+                for si in range(len(seq_shapes)):
+                    getattr(model.student, f"p{si}").add_(torch.randn(*seq_shapes[si], generator=gg) * 0.1)
+                    d[f"seq.{name}.student{it + 1}.{si}"] = getattr(model.student, f"p{si}").detach().numpy().copy()
+            hook.after_train_iter(runner)
+            hook_moms.append(hook.momentum)
+            for si in range(len(seq_shapes)):
+                d[f"seq.{name}.teacher{it + 1}.{si}"] = getattr(model.teacher, f"p{si}").detach().numpy().copy()
+        d[f"seq.{name}.logged_momentum"] = np.asarray(moms, np.float64)
+        d[f"seq.{name}.hook_momentum"] = np.asarray(hook_moms, np.float64)
+        d[f"seq.{name}.buf_end"] = model.teacher.buf.numpy().copy()
+        d[f"seq.{name}.cfg"] = np.asarray([cfg["momentum"], cfg["interval"], cfg["warm_up"], cfg.get("decay_factor", 0.1)]
+                                          + list(cfg.get("decay_intervals") or []), np.float64)
     np.savez_compressed(os.path.join(OUT, "ema.npz"), **d)
 
 

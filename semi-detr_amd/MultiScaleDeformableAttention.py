@@ -18,7 +18,10 @@ import torch  # noqa: F401  (libtorch must be loaded before the extension)
 from . import _lib
 
 try:
-    from . import _msda_ext
+    if _lib.EXPERIMENTS:      # the front end linked against libsemidetr_hip_exp.so
+        from . import _msda_ext_exp as _msda_ext
+    else:
+        from . import _msda_ext
 except ImportError as e:      # not built (or built against another torch): fail loudly, never degrade
     raise _lib.NativeLibraryError(
         "semi-detr_amd/_msda_ext*.so is missing or does not load (%s): build it with "
@@ -31,3 +34,7 @@ ms_deform_attn_fused_forward = _msda_ext.ms_deform_attn_fused_forward
 ms_deform_attn_fused_backward = _msda_ext.ms_deform_attn_fused_backward
 fused_supported = _msda_ext.fused_supported
 pyramid_check = _msda_ext.pyramid_check
+
+if _msda_ext.abi_version() != _lib.lib().semidetr_abi_version():      # a stale front end against a newer library
+    raise _lib.NativeLibraryError("semi-detr_amd/_msda_ext*.so was built against ABI %d, libsemidetr_hip.so is ABI %d: rebuild "
+                                  "(make -C semi-detr_amd/csrc)" % (_msda_ext.abi_version(), _lib.lib().semidetr_abi_version()))

@@ -7,7 +7,11 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsemidetr_hip.so")
+# SEMIDETR_EXPERIMENTS=1 (tests that force kernel variants, tools/, bench.py's HBM-peak probe) selects the experiments
+# build: the same sources with every measured-and-rejected kernel variant + the tuning entry points
+# (include/semidetr_hip_experiments.h).  The product library has neither.
+EXPERIMENTS = os.environ.get("SEMIDETR_EXPERIMENTS", "0") not in ("", "0")
+LIB_PATH = os.path.join(_HERE, "csrc", "libsemidetr_hip_exp.so" if EXPERIMENTS else "libsemidetr_hip.so")
 
 c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 
@@ -34,10 +38,7 @@ SIGNATURES = {
     "semidetr_msda_backward_f64": (c_int, _MSDA_BWD),
     "semidetr_msda_fused_forward_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 2 + [c_int] * 8 + [c_void_p]),
     "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 2 + [c_int] * 8 + [c_void_p] * 3),
-    "semidetr_msda_set_variant": (None, [c_int, c_int]),
     "semidetr_msda_last_kernels": (ctypes.c_char_p, []),
-    "semidetr_debug_counters": (c_int, [c_void_p, c_int]),
-    "semidetr_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
     "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "semidetr_lsap_solve": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 6),
@@ -52,6 +53,13 @@ SIGNATURES = {
     "semidetr_tal_loss_workspace_bytes": (ctypes.c_size_t, []),
     "semidetr_tal_loss_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, ctypes.c_float, c_int] + [c_void_p] * 3),
     "semidetr_transform_bboxes_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 3),
+}
+
+# include/semidetr_hip_experiments.h: only in libsemidetr_hip_exp.so
+EXPERIMENT_SIGNATURES = {
+    "semidetr_msda_set_variant": (None, [c_int, c_int]),
+    "semidetr_debug_counters": (c_int, [c_void_p, c_int]),
+    "semidetr_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int]),
 }
 
 _lib = None
@@ -70,7 +78,8 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C semi-detr_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        table = dict(SIGNATURES, **EXPERIMENT_SIGNATURES) if EXPERIMENTS else SIGNATURES
+        for name, (res, args) in table.items():
             fn = getattr(handle, name)       # AttributeError if the .so is stale / symbol missing
             fn.restype, fn.argtypes = res, args
         _lib = handle
@@ -87,3 +96,12 @@ def check(rc, what):
 def current_stream_ptr():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def set_variant(fwd, bwd):
+    """Force a kernel variant (experiments build only).  (0, 0) is always accepted: the product library has no variants."""
+    if EXPERIMENTS:
+        lib().semidetr_msda_set_variant(int(fwd), int(bwd))
+    elif (fwd, bwd) != (0, 0):
+        raise NativeLibraryError("kernel variants exist only in the experiments build: set SEMIDETR_EXPERIMENTS=1 "
+                                 "(libsemidetr_hip_exp.so) before importing semi_detr_amd")

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kDestThreads, 4) void msda_bwd_dest_d32(
         auto lap = [&](int slot_) {
             if (DBG >= 2 && tid == 0) {
                 const unsigned long long now = __builtin_readcyclecounter();
-                atomicAdd(&g_dest_dbg[slot_], now - tmark);
+                SEMIDETR_DBG_ADD(slot_, now - tmark);
                 tmark = now;
             } else if (DBG >= 2) {
                 tmark = 0;

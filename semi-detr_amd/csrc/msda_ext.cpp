@@ -78,6 +78,7 @@ Dims op_dims(const at::Tensor &value, const at::Tensor &shapes, const at::Tensor
 struct PyramidEntry {
     c10::weak_intrusive_ptr<c10::TensorImpl> shapes, starts;
     uint32_t v_shapes, v_starts;
+    const void *p_shapes, *p_starts;
     int64_t S;
     int result;
 };
@@ -89,14 +90,21 @@ int pyramid_check(const at::Tensor &shapes, const at::Tensor &starts, int64_t S)
 {
     auto *is = shapes.unsafeGetTensorImpl();
     auto *it = starts.unsafeGetTensorImpl();
-    {
+    // Inference tensors have no version counter (torch.inference_mode(): "Inference tensors do not track version
+    // counter"): the cache cannot tell whether they changed, so they are checked on every call.
+    const bool cacheable = !shapes.is_inference() && !starts.is_inference();
+    if (cacheable) {
         std::lock_guard<std::mutex> lock(g_pyr_mutex);
         for (auto &e : g_pyr_cache) {
             if (e.S != S || e.shapes._unsafe_get_target() != is || e.starts._unsafe_get_target() != it) continue;
             auto a = e.shapes.lock();      // expired (address reused by a new tensor) -> nullptr
             auto b = e.starts.lock();
+            // also keyed on the storage address: `t.data = other` re-points a tensor without touching its version.
+            // (In-place writes through `t.data` itself bump no counter anyone can see -- as for torch's own autograd
+            // checks, that is outside what a version-based cache can notice.)
             if (a && b && e.v_shapes == is->version_counter().current_version() &&
-                e.v_starts == it->version_counter().current_version())
+                e.v_starts == it->version_counter().current_version() && e.p_shapes == shapes.data_ptr() &&
+                e.p_starts == starts.data_ptr())
                 return e.result;
         }
     }
@@ -112,11 +120,13 @@ int pyramid_check(const at::Tensor &shapes, const at::Tensor &starts, int64_t S)
         sum += ps[2 * l] * ps[2 * l + 1];
     }
     const int result = (sum == S ? 1 : 0) | (tiles && sum == S ? 2 : 0);
+    if (!cacheable) return result;
     std::lock_guard<std::mutex> lock(g_pyr_mutex);
     if (g_pyr_cache.size() >= 16) g_pyr_cache.erase(g_pyr_cache.begin());
     g_pyr_cache.push_back({c10::weak_intrusive_ptr<c10::TensorImpl>(shapes.getIntrusivePtr()),
                            c10::weak_intrusive_ptr<c10::TensorImpl>(starts.getIntrusivePtr()),
-                           is->version_counter().current_version(), it->version_counter().current_version(), S, result});
+                           is->version_counter().current_version(), it->version_counter().current_version(),
+                           shapes.data_ptr(), starts.data_ptr(), S, result});
     return result;
 }
 
@@ -276,5 +286,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("fused_supported", &fused_supported);
     m.def("pyramid_check", &pyramid_check,
           "bit 0: sum(H*W) == S; bit 1: level_start_index tiles [0, S) exactly.  Cached per tensor pair / version.");
-    m.def("abi_version", []() { return semidetr_abi_version(); });
+    m.def("abi_version", []() { return SEMIDETR_ABI_VERSION; });      // the header this front end was compiled against
 }

@@ -95,8 +95,13 @@ struct RawIO {
 // ---------------------------------------------------------------------------------------------
 constexpr int kD = 32;
 
+#if SEMIDETR_EXPERIMENTS
 // debug / instrumentation counters of the experimental kernels (semidetr_debug_counters reads and resets them)
 __device__ unsigned long long g_dest_dbg[16];
+#define SEMIDETR_DBG_ADD(SLOT_, V_) atomicAdd(&g_dest_dbg[SLOT_], (unsigned long long)(V_))
+#else
+#define SEMIDETR_DBG_ADD(SLOT_, V_) ((void)0)
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x)
@@ -490,11 +495,12 @@ __device__ __forceinline__ void gather_body(
     const int4 *ro = rec_off + r * LPP;
     float4 *rp = rec_p + r * LPP;
     if constexpr (KLP > 0) {
-        static_assert(KLP % 8 == 0 && KLP <= 32, "results are spread over the 8 lanes of a group");
+        static_assert(KLP % 4 == 0 && KLP <= 32, "results are spread over the 8 lanes of a group");
+        constexpr int NM = (KLP + 7) / 8;          // samples kept per lane (the last one only by lanes j < KLP % 8)
         constexpr int kB = KB % 100;               // samples per batch: 4 -> 16 corner loads in flight
-        float4 mine[KLP / 8];
+        float4 mine[NM];
 #pragma unroll
-        for (int i = 0; i < KLP / 8; ++i) mine[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < NM; ++i) mine[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int P_ = KLP / L;                    // == P (checked by the launcher)
 #pragma unroll
         for (int k0 = 0; k0 < KLP; k0 += kB) {
@@ -538,24 +544,24 @@ __device__ __forceinline__ void gather_body(
         // the W / H factors of grad_sampling_loc once per kept sample, after the loop: an LDS read inside the per-sample
         // branch put an `s_waitcnt lgkmcnt(0)` on every sample of the unrolled loop
 #pragma unroll
-        for (int i = 0; i < KLP / 8; ++i) {
-            const int l = (j + 8 * i) / P_;
+        for (int i = 0; i < NM; ++i) {
+            const int l = min((j + 8 * i) / P_, L - 1);
             mine[i].y *= lev_w[l];
             mine[i].z *= lev_h[l];
         }
         float dot = 0.f;                           // fused epilogue: sum_k a_k g_k over the row
         if (IO::kSoftmax) {
 #pragma unroll
-            for (int i = 0; i < KLP / 8; ++i) dot += mine[i].w * mine[i].x;
+            for (int i = 0; i < NM; ++i) dot += (j + 8 * i < KLP) ? mine[i].w * mine[i].x : 0.f;
             dot = group8_sum(dot);
         }
         // KB >= 100: timing aid, results are computed but (practically) never stored
         if (q >= 0 && (KB < 100 || mine[0].x == 1.2345e30f)) {
             const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
 #pragma unroll
-            for (int i = 0; i < KLP / 8; ++i) {
-                const int k = j + 8 * i, l = k / P_;
-                io.store_with_dot(row, nq, LP, k, l, P_, (int)lev_h[l], (int)lev_w[l], mine[i], dot);
+            for (int i = 0; i < NM; ++i) {
+                const int k = j + 8 * i, l = min(k / P_, L - 1);
+                if (k < KLP) io.store_with_dot(row, nq, LP, k, l, P_, (int)lev_h[l], (int)lev_w[l], mine[i], dot);
             }
         }
         if (!PATCH) return;
@@ -1348,7 +1354,7 @@ struct FillWait {
         if (threadIdx.x == 0) {
             int it = 0;
             while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                if (++it >= spin_limit) { atomicAdd(&g_dest_dbg[15], 1ull); break; }
+                if (++it >= spin_limit) { SEMIDETR_DBG_ADD(15, 1); break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }

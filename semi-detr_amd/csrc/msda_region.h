@@ -65,7 +65,7 @@ __device__ __forceinline__ void reg_scatter_body(
     auto lap = [&](int slot_) {
         if (DBG && tid == 0) {
             const unsigned long long now = __builtin_readcyclecounter();
-            atomicAdd(&g_dest_dbg[slot_], now - tmark);
+            SEMIDETR_DBG_ADD(slot_, now - tmark);
             tmark = now;
         }
     };
@@ -288,7 +288,7 @@ __device__ __forceinline__ void reg_scatter_body(
                     // branch, with every stream of the wavefront waiting on it)
                     const int base_pix = st + y0 * W + x0;
                     auto flush = [&](int rowi) {
-                        if (DBG && l16 == 0) atomicAdd(&g_dest_dbg[12 + (l < 4 ? l : 3)], 1ull);      // flushed rows by sampling level
+                        if (DBG && l16 == 0) SEMIDETR_DBG_ADD(12 + (l < 4 ? l : 3), 1);      // flushed rows by sampling level
                         float *pr = gvs + (int64_t)(base_pix + (rowi / WW) * W + rowi % WW) * rs;
                         fp_atomic_add(pr, accv.x);
                         fp_atomic_add(pr + 16, accv.y);
@@ -335,7 +335,7 @@ __device__ __forceinline__ void reg_scatter_body(
                         fp_atomic_add(pr, en.x * g2.x);
                         fp_atomic_add(pr + 16, en.x * g2.y);
                     }
-                    if (DBG && tid == 0) atomicAdd(&g_dest_dbg[10], (unsigned long long)nmiss);
+                    if (DBG && tid == 0) SEMIDETR_DBG_ADD(10, nmiss);
                 }
                 lap(5);              // 5: walk + misses of wave 0 (the other waves' walk ends show up in the next lap 1)
             }

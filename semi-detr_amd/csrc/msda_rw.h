@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     auto lap = [&](int slot_) {
         if (DBG == 1 && tid == 0) {
             const unsigned long long now = __builtin_readcyclecounter();
-            atomicAdd(&g_dest_dbg[slot_], now - tmark);
+            SEMIDETR_DBG_ADD(slot_, now - tmark);
             tmark = now;
         }
     };
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // slot read before the next trip rewrites it
             }
             lap(8);                                // 8: out-of-window samples
-            if (DBG == 1 && tid == 0) atomicAdd(&g_dest_dbg[10], 1ull);
+            if (DBG == 1 && tid == 0) SEMIDETR_DBG_ADD(10, 1);
             // ---- results
             if (!GATHER) {
                 if (q_cur >= 0)
@@ -599,6 +599,6 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
 #undef RW_DOT4
             lap(9);                                // 9: results
         }
-        if (DBG == 1 && tid == 0) atomicAdd(&g_dest_dbg[11], 1ull);
+        if (DBG == 1 && tid == 0) SEMIDETR_DBG_ADD(11, 1);
     }
 }

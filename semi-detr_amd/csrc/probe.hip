@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "semidetr_hip_experiments.h"      // this file is only part of libsemidetr_hip_exp.so
 
 namespace {
 

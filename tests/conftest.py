@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def force_variant(fwd, bwd):
+    """Force an MSDA kernel variant for the following calls.  Variants exist only in the experiments build of the library
+    (SEMIDETR_EXPERIMENTS=1 -> libsemidetr_hip_exp.so): on the product library every non-default request is skipped --
+    tests/test_gpu_experiments.py re-runs those tests in a child process on the experiments build."""
+    import semi_detr_amd
+    if (fwd, bwd) != (0, 0) and not semi_detr_amd._lib.EXPERIMENTS:
+        pytest.skip("kernel variants need the experiments build (SEMIDETR_EXPERIMENTS=1)")
+    semi_detr_amd._lib.set_variant(fwd, bwd)
+
+
 class Golden:
     """Grouped view of one tests/golden/*.npz: g['case'] -> dict of arrays for keys 'case.<field>'."""
 
@@ -121,3 +131,52 @@ def check_full_shape(out, gv, gl, ga, loc, golden):
     starts = np.concatenate([[0], np.cumsum([h * w for h, w in FULL_LEVELS])])
     sums = np.asarray([[gv[n, starts[l]:starts[l + 1]].astype(np.float64).sum() for l in range(4)] for n in range(2)])
     np.testing.assert_allclose(sums, golden["gvalue_level_sums"], rtol=2e-6)
+
+
+def drive_mean_teacher_sequence(z, name, device, update_fn=None):
+    """Replays one `seq.<name>` hook sequence of tests/golden/ema.npz -- produced by the REFERENCE's own MeanTeacher driven
+    through before_run / before_train_iter / after_train_iter (oracle/gen_golden.py:gen_ema) -- on semi_detr_amd.MeanTeacher and
+    yields (iteration, logged momentum or nan, hook.momentum, [teacher tensors]) after every iteration.  `update_fn` replaces
+    the device kernel for the CPU test of the host logic (schedule, interval, decay, unwrapping, parameter pairing)."""
+    import types
+    import torch
+    from semi_detr_amd import MeanTeacher
+    cfgv = z[f"seq.{name}.cfg"]
+    cfg = dict(momentum=float(cfgv[0]), interval=int(cfgv[1]), warm_up=int(cfgv[2]))
+    if len(cfgv) > 4:
+        cfg.update(decay_factor=float(cfgv[3]), decay_intervals=[int(v) for v in cfgv[4:]])
+    n_par = len([k for k in z.files if k.startswith(f"seq.{name}.teacher0.")])
+
+    def net(which):
+        m = torch.nn.Module()
+        for i in range(n_par):
+            m.register_parameter(f"p{i}", torch.nn.Parameter(torch.from_numpy(z[f"seq.{name}.{which}0.{i}"].copy()).to(device)))
+        m.p0.requires_grad_(False)
+        m.register_buffer("buf", torch.from_numpy(z[f"seq.{name}.buf0"].copy()).to(device))
+        return m
+    model = torch.nn.Module()
+    model.teacher, model.student = net("teacher"), net("student")
+    hook = MeanTeacher(**cfg)
+    if update_fn is not None:
+        hook.momentum_update = lambda mdl, mom: update_fn(mdl, mom)
+    wrapped = model
+    if name == "wrapped":                      # the reference unwraps `runner.model.module` (mean_teacher.py:27-28)
+        wrapped = torch.nn.DataParallel(model) if device != "cpu" else _Wrap(model)
+    runner = types.SimpleNamespace(model=wrapped, iter=0, log_buffer=types.SimpleNamespace(output={}))
+    hook.before_run(runner)
+    for it in range(int(z["seq.iters"])):
+        runner.iter = it
+        runner.log_buffer.output.pop("ema_momentum", None)
+        hook.before_train_iter(runner)
+        logged = runner.log_buffer.output.get("ema_momentum", float("nan"))
+        with torch.no_grad():
+            for i in range(n_par):
+                getattr(model.student, f"p{i}").copy_(torch.from_numpy(z[f"seq.{name}.student{it + 1}.{i}"]).to(device))
+        hook.after_train_iter(runner)
+        yield it, logged, hook.momentum, [getattr(model.teacher, f"p{i}").detach().cpu().numpy() for i in range(n_par)], model
+
+
+class _Wrap(__import__("torch").nn.parallel.DistributedDataParallel.__mro__[1]):      # an nn.Module that looks like a wrapper
+    def __init__(self, module):
+        super().__init__()
+        self.module = module

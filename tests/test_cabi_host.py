@@ -11,8 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "semidetr_hip.h")).read()
+def _declared_functions(header="semidetr_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(semidetr_[a-z0-9_]+)\s*\(", src)))
 
@@ -22,11 +22,39 @@ def test_library_exports_every_declared_symbol():
     import semi_detr_amd
     names = _declared_functions()
     assert len(names) >= 12
-    handle = ctypes.CDLL(semi_detr_amd._lib.LIB_PATH)
+    csrc = os.path.join(ROOT, "semi-detr_amd", "csrc")
+    handle = ctypes.CDLL(os.path.join(csrc, "libsemidetr_hip.so"))
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/semidetr_hip.h but not exported"
     assert sorted(semi_detr_amd._lib.SIGNATURES) == names
-    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 3
+    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 4
+    # the tuning / measurement entry points live ONLY in the experiments build (not in what ships)
+    extra = _declared_functions("semidetr_hip_experiments.h")
+    assert extra == sorted(semi_detr_amd._lib.EXPERIMENT_SIGNATURES) and len(extra) == 3
+    exp = ctypes.CDLL(os.path.join(csrc, "libsemidetr_hip_exp.so"))
+    for n in names + extra:
+        assert hasattr(exp, n), f"{n} missing from libsemidetr_hip_exp.so"
+    for n in extra:
+        assert not hasattr(handle, n), f"{n} must not be exported by the product library"
+    assert exp.semidetr_abi_version() == 4
+
+
+def test_product_code_object_holds_only_reachable_msda_kernels():
+    """the product library's MSDA code object = the kernels its dispatcher can reach (28: forward patch /
+    strips x 3 splits, generic, gather x 3, region scatter, merged level scatter x 2, strips backward x 2 -- each for the
+    reference contract and the fused prologue, + fp64 generic), none of the rejected experiments."""
+    import subprocess
+    csrc = os.path.join(ROOT, "semi-detr_amd", "csrc")
+    syms = subprocess.run(["strings", "-a", os.path.join(csrc, "libsemidetr_hip.so")], capture_output=True, text=True).stdout
+    kernels = set(re.findall(r"_ZN12_GLOBAL__N_1\d+(msda_[a-z0-9_]+)I[^\n]*?\.kd", syms))
+    names = set(re.findall(r"(_ZN12_GLOBAL__N_1\d+msda_[A-Za-z0-9_]+)\.kd", syms))
+    assert 20 <= len(names) <= 30, sorted(names)
+    for banned in ("msda_bwd_dest_d32", "msda_fwd_d32_lw", "msda_fwd_d32_res", "msda_bwd_enc_merged", "msda_bwd_encreg_merged",
+                   "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "msda_rw_d32", "stream_kernel"):
+        assert banned not in syms, banned
+    assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(csrc, "libsemidetr_hip.so")],
+                                          capture_output=True, text=True).stdout
+    assert kernels >= {"msda_fwd_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged", "msda_bwd_d32"}
 
 
 def test_host_side_argument_errors_need_no_gpu():
@@ -67,7 +95,7 @@ def test_compiled_front_end_is_the_reference_module_surface():
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd
     assert type(MSDA.ms_deform_attn_forward).__name__ == "builtin_function_or_method" or "pybind" in repr(MSDA.ms_deform_attn_forward)
-    assert semi_detr_amd.MultiScaleDeformableAttention._msda_ext.abi_version() == 3
+    assert semi_detr_amd.MultiScaleDeformableAttention._msda_ext.abi_version() == 4
     sh, ls = torch.tensor([[2, 3], [1, 2]]), torch.tensor([0, 6])
     assert MSDA.pyramid_check(sh, ls, 8) == 3
     assert MSDA.pyramid_check(sh, ls, 8) == 3                      # cache hit
@@ -77,6 +105,22 @@ def test_compiled_front_end_is_the_reference_module_surface():
     assert MSDA.pyramid_check(sh, ls, 8) == 0 and MSDA.pyramid_check(sh, ls, 9) == 3
     with pytest.raises(RuntimeError, match="value tensor has to be contiguous|Not implemented on the CPU"):
         MSDA.ms_deform_attn_forward(torch.zeros(1, 4, 2, 2), sh, ls, torch.zeros(1, 1, 2, 2, 1, 2), torch.zeros(1, 1, 2, 2, 1), 64)
+
+
+def test_pyramid_check_under_inference_mode_and_data_repointing():
+    """inference tensors have no version counter (the cached check used to throw there, and with it the whole
+    MSDA path under torch.inference_mode()); `t.data = ...` re-points a tensor without bumping its version."""
+    import MultiScaleDeformableAttention as MSDA
+    with torch.inference_mode():
+        sh, ls = torch.tensor([[2, 3], [1, 2]]), torch.tensor([0, 6])
+        assert MSDA.pyramid_check(sh, ls, 8) == 3
+        assert MSDA.pyramid_check(sh, ls, 8) == 3
+        sh[1, 1] = 3                                   # allowed on an inference tensor inside inference mode; never cached
+        assert MSDA.pyramid_check(sh, ls, 8) == 0
+    sh, ls = torch.tensor([[2, 3], [1, 2]]), torch.tensor([0, 6])
+    assert MSDA.pyramid_check(sh, ls, 8) == 3
+    sh.data = torch.tensor([[2, 3], [1, 3]])            # new storage, same version counter value
+    assert MSDA.pyramid_check(sh, ls, 8) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

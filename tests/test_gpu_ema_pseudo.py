@@ -129,6 +129,23 @@ def test_mean_teacher_hook_semantics(golden_ema):
     assert abs(hook2.momentum - (1 - (1 - 0.999) / 0.1)) < 1e-12
 
 
+def test_mean_teacher_vs_reference_hook_sequences(golden_ema):
+    """semi_detr_amd.MeanTeacher with the real kernel against the sequences the reference's own hook produced
+    (tests/golden/ema.npz seq.*: before_run clone, warm-up, interval 2, decay intervals, wrapped model)."""
+    from conftest import drive_mean_teacher_sequence
+    z = golden_ema.z
+    for name in z["seq.names"]:
+        for it, logged, hook_mom, teachers, model in drive_mean_teacher_sequence(z, str(name), "cuda"):
+            want = z[f"seq.{name}.logged_momentum"][it]
+            assert (np.isnan(want) and np.isnan(logged)) or logged == want, (name, it)
+            assert hook_mom == z[f"seq.{name}.hook_momentum"][it], (name, it)
+            for i, t in enumerate(teachers):
+                ref = z[f"seq.{name}.teacher{it + 1}.{i}"]
+                ulp = np.abs(t.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max()
+                assert ulp <= 2, (name, it, i, int(ulp))
+        assert np.array_equal(model.teacher.buf.cpu().numpy(), z[f"seq.{name}.buf_end"])
+
+
 def test_pseudo_label_filter(golden_pseudo):
     from semi_detr_amd import filter_pseudo_labels
     names = golden_pseudo.names()

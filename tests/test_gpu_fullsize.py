@@ -15,7 +15,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import kink_mask
+from conftest import force_variant, kink_mask
 from test_gpu_fused import _prologue_np
 
 pytestmark = pytest.mark.gpu
@@ -45,12 +45,12 @@ def _check(out, gv, o_out, o_gv):
 @pytest.fixture(autouse=True)
 def _auto_variant():
     import os
-    import semi_detr_amd
-    # SEMIDETR_TEST_VARIANT="fwd,bwd" runs the same full-size parity checks on a forced kernel variant (tuning aid)
+    # SEMIDETR_TEST_VARIANT="fwd,bwd" (with SEMIDETR_EXPERIMENTS=1) runs the same full-size parity checks on a forced kernel
+    # variant of the experiments build (tuning aid)
     fv, bv = [int(x) for x in os.environ.get("SEMIDETR_TEST_VARIANT", "0,0").split(",")]
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(fv, bv)
+    force_variant(fv, bv)
     yield
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, 0)
+    force_variant(0, 0)
 
 
 def _encoder_case(N, levels, sigma_px, seed):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import Golden, kink_mask
+from conftest import Golden, force_variant, kink_mask
 
 pytestmark = pytest.mark.gpu
 CASES = Golden("msda.npz").names()
@@ -38,10 +38,9 @@ def _run(value, shapes, loc, attn, gout):
 
 @pytest.fixture(autouse=True)
 def _auto_variant():
-    import semi_detr_amd
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, 0)
+    force_variant(0, 0)
     yield
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(0, 0)
+    force_variant(0, 0)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -90,8 +89,7 @@ def _random_case(seed, shapes, N, M, D, Lq, P, dtype, wide=True):
 def test_fast_path_variants_vs_oracle(variants, Lq):
     """Every forced kernel variant of the fp32 / D=32 path (forward split 1/2/4, backward 8/32 rows per
     workgroup, and the generic kernel = 99), ragged query counts around the tile sizes."""
-    import semi_detr_amd
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(*variants)
+    force_variant(*variants)
     case = _random_case(40 + Lq, [(20, 27), (10, 14), (5, 7), (3, 4)], 2, 8, 32, Lq, 4, np.float32)
     out, gv, gl, ga = _run(*case)
     o_out = oracle.msda_forward(*case[:4])
@@ -134,8 +132,7 @@ def test_encoder_self_attention_vs_oracle(shapes, M, P, mode, variant):
         pytest.skip("the windowed backward is specialised for num_point == 4")
     if variant[0] >= 700 and (P != 4 or len(shapes) not in (4, 5)):
         pytest.skip("the region-window kernels are built for num_point == 4 and 4 or 5 levels")
-    import semi_detr_amd
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(*variant)
+    force_variant(*variant)
     rng = np.random.default_rng(len(shapes) * 100 + M + P)
     shp = np.asarray(shapes, np.int64)
     L, N, D = len(shapes), 2, 32

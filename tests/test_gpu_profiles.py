@@ -19,7 +19,6 @@ def test_traffic_json_matches_the_kernels_the_library_launches():
     import MultiScaleDeformableAttention as MSDA
     pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
     lib = sda._lib.lib()
-    lib.semidetr_msda_set_variant(0, 0)
     dev = torch.device("cuda:0")
     shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
     starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])

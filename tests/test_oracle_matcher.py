@@ -107,6 +107,36 @@ def test_oracle_ema(golden_ema):
     assert worst <= 1, f"EMA oracle differs from torch by {worst} ulp"
 
 
+def test_mean_teacher_host_logic_vs_reference_hook_sequences(golden_ema, monkeypatch):
+    """The hook's host side (schedule :46-48, interval, initial clone :32-35, decay :52-58, wrapper unwrapping :27-28,
+    positional parameter pairing incl. frozen parameters, buffers untouched) replayed against sequences the REFERENCE's own
+    MeanTeacher produced; the device kernel is replaced by the oracle's update here (the GPU test runs the real one)."""
+    import torch
+    from conftest import drive_mean_teacher_sequence
+    import semi_detr_amd.mean_teacher as mt
+    monkeypatch.setattr(mt, "is_module_wrapper", lambda m: hasattr(m, "module") and not hasattr(m, "teacher"))
+
+    def cpu_update(model, mom):
+        for (_, ps), (_, pt) in zip(model.student.named_parameters(), model.teacher.named_parameters()):
+            t = pt.detach().numpy()
+            oracle.ema_update(t, ps.detach().numpy(), float(mom))
+
+    z = golden_ema.z
+    for name in z["seq.names"]:
+        steps = 0
+        for it, logged, hook_mom, teachers, model in drive_mean_teacher_sequence(z, str(name), "cpu", cpu_update):
+            want = z[f"seq.{name}.logged_momentum"][it]
+            assert (np.isnan(want) and np.isnan(logged)) or logged == want, (name, it, logged, want)
+            assert hook_mom == z[f"seq.{name}.hook_momentum"][it], (name, it)
+            for i, t in enumerate(teachers):
+                ref = z[f"seq.{name}.teacher{it + 1}.{i}"]
+                ulp = np.abs(t.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max()
+                assert ulp <= 2, (name, it, i, int(ulp))       # oracle rounding vs torch CPU: <= 1 ulp per update
+            steps += 1
+        assert steps == int(z["seq.iters"])
+        assert np.array_equal(model.teacher.buf.numpy(), z[f"seq.{name}.buf_end"])       # buffers are never averaged
+
+
 def test_oracle_pseudo(golden_pseudo):
     for name in golden_pseudo.names():
         g = golden_pseudo[name]

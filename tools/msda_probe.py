@@ -7,6 +7,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("SEMIDETR_EXPERIMENTS", "1")      # kernel variants live in the experiments build
 import torch  # noqa: E402
 
 import bench  # noqa: E402
@@ -26,7 +27,7 @@ def main():
     a = ap.parse_args()
     import semi_detr_amd as sda
     import MultiScaleDeformableAttention as MSDA
-    sda._lib.lib().semidetr_msda_set_variant(a.variant if a.fvariant is None else a.fvariant, a.variant)
+    sda._lib.set_variant(a.variant if a.fvariant is None else a.fvariant, a.variant)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     S, M, D, L, P, LEVELS = bench.S, bench.M, bench.D, bench.L, bench.P, bench.LEVELS

@@ -1,5 +1,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os as _os
+_os.environ.setdefault("SEMIDETR_EXPERIMENTS", "1")
 import torch, bench
 import semi_detr_amd as sda
 import MultiScaleDeformableAttention as MSDA
@@ -8,7 +10,7 @@ dev = torch.device("cuda:0")
 wl_shapes = torch.as_tensor(bench.LEVELS, dtype=torch.long, device=dev)
 v, sh, st, loc, attn, gout, Sx, Lx, lq = bench._msda_case(dev, bench.LEVELS, 4, 0, True)
 gout = torch.rand_like(gout)
-lib.semidetr_msda_set_variant(0, int(sys.argv[1]) if len(sys.argv) > 1 else 73)
+sda._lib.set_variant(0, int(sys.argv[1]) if len(sys.argv) > 1 else 73)
 buf = (ctypes.c_ulonglong * 16)()
 MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, gout, 64); torch.cuda.synchronize()
 lib.semidetr_debug_counters(ctypes.cast(buf, ctypes.c_void_p), 1)

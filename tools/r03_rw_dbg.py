@@ -1,6 +1,7 @@
 """Per-phase cycle counts of the instrumented region-window kernel (forward variant 707 / backward 7007)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("SEMIDETR_EXPERIMENTS", "1")
 import torch, bench
 import semi_detr_amd as sda
 import MultiScaleDeformableAttention as MSDA
@@ -10,7 +11,7 @@ v, sh, st, loc, attn, gout, Sx, Lx, lq = bench._msda_case(dev, bench.LEVELS, 4, 
 gout = torch.rand_like(gout)
 names = ["setup", "stage_issue", "boundary_wait", "stage_store", "store_wait", "geometry", "next_loads", "compute", "outside", "results"]
 for which in ("fwd", "bwd"):
-    lib.semidetr_msda_set_variant(707, 7007)
+    sda._lib.set_variant(707, 7007)
     buf = (ctypes.c_ulonglong * 16)()
     run = (lambda: MSDA.ms_deform_attn_forward(v, sh, st, loc, attn, 64)) if which == "fwd" else \
           (lambda: MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, gout, 64))

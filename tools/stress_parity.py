@@ -9,6 +9,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
+import os as _os
+_os.environ.setdefault("SEMIDETR_EXPERIMENTS", "1")
 import torch  # noqa: E402
 
 import oracle  # noqa: E402
@@ -23,7 +25,7 @@ def main():
     a = ap.parse_args()
     import semi_detr_amd  # noqa: F401  (installs the module below)
     import MultiScaleDeformableAttention as MSDA
-    semi_detr_amd._lib.lib().semidetr_msda_set_variant(*a.variant)
+    semi_detr_amd._lib.set_variant(*a.variant)
     rng = np.random.default_rng(a.seed)
     skipped = 0
     worst = dict(out=0.0, gv=0.0, gl=0.0, ga=0.0)
