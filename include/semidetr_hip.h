@@ -275,6 +275,8 @@ int semidetr_transform_bboxes_f32(void *stream, const float *boxes, int box_stri
  * Batch layout as semidetr_match_cost_f32 (gt_offsets (B+1,) int32 DEVICE, img_wh (B,2) fp32 DEVICE = (w, h)),
  * but cls_prob (B,Q,C) holds PROBABILITIES (the call site passes cls_score.sigmoid(), head.py:1111).
  * max_gt_per_problem >= every G_b (<= 1024); Q <= 2048; candidate_topk <= Q unless total_gt == 0.
+ * dynamic_k != 0 = the `teacher_assign and multiple_pos` option (o2m_assigner.py:125-133): per ground truth the first k_g of its
+ * top-candidate_topk candidates are positive whatever their metric, k_g = max(1, int(sum of its candidate_topk largest IoUs)).
  * Outputs, all (B,Q[,4]):
  *   gt_inds int64 (0 background, g+1 positive), labels int64 (class of the gt or -1),
  *   max_overlaps fp32 (IoU with the assigned gt; -1e8 when unassigned; 0 for a problem without gts),
@@ -285,7 +287,7 @@ int semidetr_transform_bboxes_f32(void *stream, const float *boxes, int box_stri
 int semidetr_o2m_assign_f32(void *stream, const float *bbox_pred, const float *cls_prob, const float *gt_bboxes,
                             const int64_t *gt_labels, const int32_t *gt_offsets, const float *img_wh,
                             int num_problems, int num_query, int num_classes, int total_gt,
-                            int max_gt_per_problem, int candidate_topk, float alpha, float beta,
+                            int max_gt_per_problem, int candidate_topk, int dynamic_k, float alpha, float beta,
                             int64_t *gt_inds, int64_t *labels, float *max_overlaps, float *assign_metrics,
                             int64_t *labels_full, float *bbox_targets, float *norm_metrics);
 

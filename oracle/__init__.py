@@ -189,7 +189,7 @@ def transform_bboxes(boxes, M, out_h, out_w):
     return out
 
 
-def o2m_assign(bbox_pred, cls_prob, gt_bboxes, gt_labels, img_w, img_h, topk=13, alpha=1.0, beta=6.0):
+def o2m_assign(bbox_pred, cls_prob, gt_bboxes, gt_labels, img_w, img_h, topk=13, alpha=1.0, beta=6.0, dynamic_k=False):
     """One image -> (gt_inds int64, labels int64, max_overlaps f32, assign_metrics f32); o2m_oracle.c
     (o2m_assigner.py:50-170)."""
     bbox_pred, cls_prob = _c(bbox_pred, np.float32), _c(cls_prob, np.float32)
@@ -199,10 +199,10 @@ def o2m_assign(bbox_pred, cls_prob, gt_bboxes, gt_labels, img_w, img_h, topk=13,
     mo, am = np.zeros(max(Q, 1), np.float32), np.zeros(max(Q, 1), np.float32)
     fn = lib().o2m_assign_oracle
     fn.restype = None
-    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, ctypes.c_int,
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                                                 ctypes.c_float, ctypes.c_float] + [ctypes.c_void_p] * 4
     fn(_p(bbox_pred), _p(cls_prob), _p(gt_bboxes), _p(gt_labels), Q, C, G, float(img_w), float(img_h), int(topk),
-       float(alpha), float(beta), _p(gi), _p(lab), _p(mo), _p(am))
+       int(bool(dynamic_k)), float(alpha), float(beta), _p(gi), _p(lab), _p(mo), _p(am))
     return gi[:Q], lab[:Q], mo[:Q], am[:Q]
 
 

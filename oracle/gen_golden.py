@@ -751,6 +751,13 @@ def gen_o2m(tr):
         prob = torch.rand(Q, C, generator=g) ** 2
         meta = dict(img_shape=(ih, iw, 3))
         res = assigner.assign(bp, prob, gt, gl, meta)
+        # the teacher's two options (o2m_assigner.py:115-133): best-aligned candidate only / dynamic k
+        for tag, kw in (("t1", dict(teacher_assign=True)), ("tk", dict(teacher_assign=True, multiple_pos=True))):
+            rt = assigner.assign(bp, prob, gt, gl, meta, **kw)
+            d[f"{name}.{tag}_gt_inds"] = rt.gt_inds.numpy().astype(np.int64)
+            d[f"{name}.{tag}_labels"] = rt.labels.numpy().astype(np.int64)
+            d[f"{name}.{tag}_max_overlaps"] = rt.max_overlaps.numpy()
+            d[f"{name}.{tag}_assign_metrics"] = rt.assign_metrics.numpy()
         # ---- head.py:1114-1160
         INF = 100000000
         assign_ious = res.max_overlaps.clone()

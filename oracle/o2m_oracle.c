@@ -41,7 +41,7 @@ static float iou_(const float *p, const float *g)      /* iou2d_calculator.py:23
 /* One image.  cls_prob (Q,C) probabilities (the call site passes cls_score.sigmoid(), head.py:1111).
  * gt_inds, labels (Q,) int64; max_overlaps, assign_metrics (Q,) fp32. */
 void o2m_assign_oracle(const float *bbox_pred, const float *cls_prob, const float *gt_bboxes, const int64_t *gt_labels,
-                       int Q, int C, int G, float img_w, float img_h, int topk, float alpha, float beta,
+                       int Q, int C, int G, float img_w, float img_h, int topk, int dynamic_k, float alpha, float beta,
                        int64_t *gt_inds, int64_t *labels, float *max_overlaps, float *assign_metrics)
 {
     for (int q = 0; q < Q; ++q) { gt_inds[q] = G == 0 ? 0 : -1; labels[q] = -1; max_overlaps[q] = 0.f; assign_metrics[q] = 0.f; }
@@ -60,14 +60,29 @@ void o2m_assign_oracle(const float *bbox_pred, const float *cls_prob, const floa
         }
     }
     const int k = topk < Q ? topk : Q;
-    for (int g = 0; g < G; ++g) {                                         /* topk per gt, is_pos = metric > 0 */
+    for (int g = 0; g < G; ++g) {                                         /* topk per gt */
+        int kpos = k;
+        if (dynamic_k) {                                                  /* o2m_assigner.py:125-133: k_g = clamp(int(sum of the */
+            float sum = 0.f;                                              /* top-k IoUs), min=1), added in descending order      */
+            for (int q = 0; q < Q; ++q) taken[q] = 0;
+            for (int r = 0; r < k; ++r) {
+                int best = -1;
+                for (int q = 0; q < Q; ++q)
+                    if (!taken[q] && (best < 0 || iou[(size_t)q * G + g] > iou[(size_t)best * G + g])) best = q;
+                taken[best] = 1;
+                sum += iou[(size_t)best * G + g];
+            }
+            kpos = (int)sum < 1 ? 1 : (int)sum;
+            if (kpos > k) kpos = k;
+        }
         for (int q = 0; q < Q; ++q) taken[q] = 0;
-        for (int r = 0; r < k; ++r) {
+        for (int r = 0; r < kpos; ++r) {
             int best = -1;
             for (int q = 0; q < Q; ++q)
                 if (!taken[q] && (best < 0 || met[(size_t)q * G + g] > met[(size_t)best * G + g])) best = q;
             taken[best] = 1;
-            if (met[(size_t)best * G + g] > 0.f) inf[(size_t)best * G + g] = iou[(size_t)best * G + g];
+            /* is_pos: metric > 0 (:135), or -- dynamic k -- simply being among the first k_g candidates (:128-133) */
+            if (dynamic_k || met[(size_t)best * G + g] > 0.f) inf[(size_t)best * G + g] = iou[(size_t)best * G + g];
         }
     }
     for (int q = 0; q < Q; ++q) {                                         /* max over gts, first maximum wins */

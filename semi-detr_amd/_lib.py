@@ -49,7 +49,7 @@ SIGNATURES = {
     "semidetr_nms_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "semidetr_pseudo_nms_f32": (c_int, [c_void_p] * 4 + [c_int] * 3 + [ctypes.c_float, ctypes.c_float, c_int, c_void_p,
                                                                        ctypes.c_size_t] + [c_void_p] * 3),
-    "semidetr_o2m_assign_f32": (c_int, [c_void_p] * 7 + [c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [c_void_p] * 7),
+    "semidetr_o2m_assign_f32": (c_int, [c_void_p] * 7 + [c_int] * 7 + [ctypes.c_float, ctypes.c_float] + [c_void_p] * 7),
     "semidetr_tal_loss_workspace_bytes": (ctypes.c_size_t, []),
     "semidetr_tal_loss_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, ctypes.c_float, c_int] + [c_void_p] * 3),
     "semidetr_transform_bboxes_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 3),

@@ -66,7 +66,9 @@ struct O2mOut {
 };
 
 // NQL = queries per lane (registers): 16 -> Q <= 1024, 32 -> Q <= 2048
-template <int NQL>
+// DYN: the teacher's `multiple_pos` option (o2m_assigner.py:125-133): per ground truth the first k_g of its top-`topk`
+// candidates (by metric) are positive, k_g = max(1, int(sum of its `topk` largest IoUs)); no `metric > 0` filter.
+template <int NQL, bool DYN = false>
 __global__ __launch_bounds__(256) void o2m_assign_kernel(
     const float *__restrict__ bbox_pred, const float *__restrict__ cls_prob, const float *__restrict__ gt_bboxes,
     const int64_t *__restrict__ gt_labels, const int32_t *__restrict__ gt_offsets, const float *__restrict__ img_wh,
@@ -116,17 +118,48 @@ __global__ __launch_bounds__(256) void o2m_assign_kernel(
             if (q < Q && (unsigned)label < (unsigned)C)
                 met[t] = ipow_(probs[(size_t)q * C + label], alpha) * ipow_(iou_(pb[q], gt), beta);
         }
-        for (int r = 0; r < topk; ++r) {
+        int rounds = topk;
+        if (DYN) {
+            // k_g: the sum of the ground truth's `topk` largest IoUs (taken in descending order, as torch.topk returns
+            // them), truncated, at least 1
+            float iv[NQL];
+#pragma unroll
+            for (int t = 0; t < NQL; ++t) {
+                const int q = lane + 64 * t;
+                iv[t] = q < Q ? iou_(pb[q], gt) : -1.f;
+            }
+            float sum = 0.f;
+            for (int r = 0; r < topk; ++r) {
+                float bv = -1.f;
+                int bt = 0;
+#pragma unroll
+                for (int t = 0; t < NQL; ++t)
+                    if (iv[t] > bv) { bv = iv[t]; bt = t; }
+                const unsigned long long mine = bv >= 0.f ? ((unsigned long long)(__float_as_uint(bv) + 1u) << 32) |
+                                                                (unsigned)(0xFFFFFFFFu - (unsigned)(lane + 64 * bt)) : 0ull;
+                const unsigned long long win = wave_max_u64(mine);
+                if (win == 0) break;
+                sum += __uint_as_float((unsigned)(win >> 32) - 1u);
+                if (win == mine) {
+#pragma unroll
+                    for (int t = 0; t < NQL; ++t)
+                        if (t == bt) iv[t] = -1.f;
+                }
+            }
+            rounds = min(topk, max((int)sum, 1));
+        }
+        for (int r = 0; r < rounds; ++r) {
             float bv = -1.f;
             int bt = 0;
 #pragma unroll
             for (int t = 0; t < NQL; ++t)
                 if (met[t] > bv) { bv = met[t]; bt = t; }          // first maximum = smallest query of the lane
             const int bq = lane + 64 * bt;
-            const unsigned long long mine = bv >= 0.f ? ((unsigned long long)__float_as_uint(bv) << 32) |
+            // DYN: a candidate with metric 0 is still a candidate -- the key's high word is (bits + 1), 0 = nothing left
+            const unsigned long long mine = bv >= 0.f ? ((unsigned long long)(__float_as_uint(bv) + (DYN ? 1u : 0u)) << 32) |
                                                             (unsigned)(0xFFFFFFFFu - (unsigned)bq) : 0ull;
             const unsigned long long win = wave_max_u64(mine);
-            if ((win >> 32) == 0) break;           // best remaining metric is 0 (or nothing left): is_pos is false from here on
+            if ((win >> 32) == 0) break;           // !DYN: best remaining metric is 0 (or nothing left): is_pos is false from here on
             if (win == mine) {
 #pragma unroll
                 for (int t = 0; t < NQL; ++t)
@@ -184,8 +217,8 @@ __global__ __launch_bounds__(256) void o2m_assign_kernel(
 extern "C" int semidetr_o2m_assign_f32(void *stream, const float *bbox_pred, const float *cls_prob,
                                        const float *gt_bboxes, const int64_t *gt_labels, const int32_t *gt_offsets,
                                        const float *img_wh, int num_problems, int num_query, int num_classes,
-                                       int total_gt, int max_gt_per_problem, int candidate_topk, float alpha,
-                                       float beta, int64_t *gt_inds, int64_t *labels, float *max_overlaps,
+                                       int total_gt, int max_gt_per_problem, int candidate_topk, int dynamic_k,
+                                       float alpha, float beta, int64_t *gt_inds, int64_t *labels, float *max_overlaps,
                                        float *assign_metrics, int64_t *labels_full, float *bbox_targets,
                                        float *norm_metrics)
 {
@@ -206,11 +239,11 @@ extern "C" int semidetr_o2m_assign_f32(void *stream, const float *bbox_pred, con
                      "o2m_assign: bbox_pred / gt_bboxes / bbox_targets must be 16-byte aligned");
     const O2mOut out = {gt_inds, labels, max_overlaps, assign_metrics, labels_full, bbox_targets, norm_metrics};
     hipStream_t st = semidetr::as_stream(stream);
-    if (Q <= 1024)
-        hipLaunchKernelGGL(o2m_assign_kernel<16>, dim3(B), dim3(256), 0, st, bbox_pred, cls_prob, gt_bboxes, gt_labels,
-                           gt_offsets, img_wh, Q, C, candidate_topk, alpha, beta, (int64_t)C, out);
-    else
-        hipLaunchKernelGGL(o2m_assign_kernel<32>, dim3(B), dim3(256), 0, st, bbox_pred, cls_prob, gt_bboxes, gt_labels,
-                           gt_offsets, img_wh, Q, C, candidate_topk, alpha, beta, (int64_t)C, out);
+#define O2M_LAUNCH(NQL_, DYN_)                                                                                       \
+    hipLaunchKernelGGL((o2m_assign_kernel<NQL_, DYN_>), dim3(B), dim3(256), 0, st, bbox_pred, cls_prob, gt_bboxes, gt_labels, \
+                       gt_offsets, img_wh, Q, C, candidate_topk, alpha, beta, (int64_t)C, out)
+    if (Q <= 1024) { if (dynamic_k) O2M_LAUNCH(16, true); else O2M_LAUNCH(16, false); }
+    else { if (dynamic_k) O2M_LAUNCH(32, true); else O2M_LAUNCH(32, false); }
+#undef O2M_LAUNCH
     return semidetr::launch_status("o2m_assign_kernel");
 }

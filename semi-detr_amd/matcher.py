@@ -348,7 +348,7 @@ class O2MAssigner:
         self.debug = debug
 
     def assign_batch(self, bbox_preds, cls_probs, gt_bboxes_list, gt_labels_list, img_metas, alpha=1, beta=6,
-                     candidate_topk=None):
+                     candidate_topk=None, dynamic_k=False):
         """bbox_preds (B,Q,4) normalised cxcywh, cls_probs (B,Q,C) PROBABILITIES (``cls_score.sigmoid()``), one gt
         tensor pair and one img_meta per problem.  Returns dict(gt_inds, labels, max_overlaps, assign_metrics
         (each (B,Q)), labels_full (B,Q), bbox_targets (B,Q,4), norm_metrics (B,Q), num_gts list)."""
@@ -376,7 +376,8 @@ class O2MAssigner:
         with torch.cuda.device(dev):
             rc = _lib.lib().semidetr_o2m_assign_f32(
                 _lib.current_stream_ptr(), _p(bp), _p(cp), _p(gt_b), _p(gt_l), _p(offs_dev), _p(wh), B, Q, C, offs[-1],
-                max(counts) if counts else 0, int(k), float(alpha), float(beta), _p(out["gt_inds"]), _p(out["labels"]),
+                max(counts) if counts else 0, int(k), int(bool(dynamic_k)), float(alpha), float(beta), _p(out["gt_inds"]),
+                _p(out["labels"]),
                 _p(out["max_overlaps"]), _p(out["assign_metrics"]), _p(out["labels_full"]), _p(out["bbox_targets"]),
                 _p(out["norm_metrics"]))
         _lib.check(rc, "semidetr_o2m_assign_f32")
@@ -386,10 +387,10 @@ class O2MAssigner:
     def assign(self, bbox_pred, cls_pred, gt_bboxes, gt_labels, img_meta, gt_bboxes_ignore=None, alpha=1, beta=6,
                teacher_assign=False, multiple_pos=False):
         assert gt_bboxes_ignore is None, "Only case when gt_bboxes_ignore is None is supported."
-        if teacher_assign and multiple_pos:
-            raise NotImplementedError("O2MAssigner: teacher_assign with multiple_pos (dynamic k) has no caller in the "
-                                      "reference and is not built")
-        k = 1 if teacher_assign else self.candidate_topk       # o2m_assigner.py:115-122
-        r = self.assign_batch(bbox_pred[None], cls_pred[None], [gt_bboxes], [gt_labels], [img_meta], alpha, beta, k)
+        # o2m_assigner.py:115-133: the teacher keeps only the best-aligned candidate (option 1), or -- multiple_pos -- the
+        # first k_g of the top-k candidates with k_g estimated from the ground truth's top-k IoUs (option 2)
+        k = 1 if (teacher_assign and not multiple_pos) else self.candidate_topk
+        r = self.assign_batch(bbox_pred[None], cls_pred[None], [gt_bboxes], [gt_labels], [img_meta], alpha, beta, k,
+                              dynamic_k=bool(teacher_assign and multiple_pos))
         return O2MAssignResult(r["num_gts"][0], r["gt_inds"][0], r["max_overlaps"][0], r["assign_metrics"][0],
                                labels=r["labels"][0])

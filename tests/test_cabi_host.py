@@ -182,9 +182,6 @@ def test_assigner_surface_and_registry():
     assert o.candidate_topk == 13 and s.O2MAssigner(candidate_topk=5).candidate_topk == 5
     with pytest.raises(AssertionError, match="gt_bboxes_ignore"):
         o.assign(torch.zeros(1, 4), torch.zeros(1, 2), torch.zeros(0, 4), torch.zeros(0), {}, gt_bboxes_ignore=1)
-    with pytest.raises(NotImplementedError):
-        o.assign(torch.zeros(1, 4), torch.zeros(1, 2), torch.zeros(0, 4), torch.zeros(0), {}, teacher_assign=True,
-                 multiple_pos=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         o.assign(torch.zeros(20, 4), torch.zeros(20, 2), torch.zeros(1, 4), torch.zeros(1), dict(img_shape=(4, 4, 3)))
     h = s.MeanTeacher(momentum=0.999, interval=1, warm_up=0)
@@ -197,3 +194,84 @@ def test_graft_entry_build_runs():
     """The driver's build check: make (incremental) for the HIP library and the oracle, import, ABI version."""
     import __graft_entry__
     __graft_entry__.build()
+
+
+def test_plugin_surface_builds_from_the_reference_config_dicts(monkeypatch):
+    """`registry.register_all()` against registries that behave like mmcv's (register_module(name, force,
+    module) / build(cfg)), pre-populated with placeholder classes under the reference's names (what importing detr_od /
+    detr_ssod would have registered), then every object built from the LITERAL dicts of the reference's configs:
+    configs/dino_detr/dino_detr_r50_8x2_12e_coco.py:40-44, configs/dino_detr/dino_detr_ssod_r50_coco_120k.py:30-34,45-51,
+    configs/detr_ssod/detr_ssod_dino_detr_r50_coco_120k.py:43."""
+    import sys
+    import types
+
+    class Registry:                       # the part of mmcv.utils.Registry the plugin surface uses
+        def __init__(self, name):
+            self.name, self.module_dict = name, {}
+
+        def register_module(self, name=None, force=False, module=None):
+            def _reg(cls):
+                key = name or cls.__name__
+                if not force and key in self.module_dict:
+                    raise KeyError(f"{key} is already registered in {self.name}")
+                self.module_dict[key] = cls
+                return cls
+            return _reg(module) if module is not None else _reg
+
+        def build(self, cfg):
+            args = dict(cfg)
+            return self.module_dict[args.pop("type")](**args)
+
+    regs = {k: Registry(k) for k in ("BBOX_ASSIGNERS", "MATCH_COST", "LOSSES", "HOOKS", "MODULE_WRAPPERS")}
+    names = {"BBOX_ASSIGNERS": ["HungarianAssigner", "O2MAssigner"], "MATCH_COST": ["FocalLossCost", "BBoxL1Cost", "IoUCost"],
+             "LOSSES": ["TaskAlignedFocalLoss"], "HOOKS": ["MeanTeacher"]}
+    for reg, ns in names.items():         # the reference's own classes are registered first; force=True must replace them
+        for n in ns:
+            regs[reg].register_module(name=n, module=type(n, (), {"placeholder": True}))
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        monkeypatch.setitem(sys.modules, name, m)
+    for pkg in ("mmdet", "mmdet.core", "mmdet.core.bbox", "mmdet.core.bbox.match_costs", "mmdet.models", "mmcv", "mmcv.runner"):
+        mod(pkg)
+    mod("mmdet.core.bbox.builder", BBOX_ASSIGNERS=regs["BBOX_ASSIGNERS"])
+    mod("mmdet.core.bbox.match_costs.builder", MATCH_COST=regs["MATCH_COST"])
+    mod("mmdet.models.builder", LOSSES=regs["LOSSES"])
+    mod("mmcv.runner.hooks", HOOKS=regs["HOOKS"], Hook=object)
+    mod("mmcv.parallel", MODULE_WRAPPERS=regs["MODULE_WRAPPERS"])
+
+    import semi_detr_amd as s
+    from semi_detr_amd import registry
+    with pytest.raises(KeyError, match="already registered"):
+        registry.register_all(force=False)
+    done, skipped = registry.register_all()
+    assert skipped == [] and sorted(done) == sorted(["HungarianAssigner", "O2MAssigner", "BBoxL1Cost", "FocalLossCost", "IoUCost",
+                                                    "MeanTeacher", "TaskAlignedFocalLoss", "FlatDDP"])
+    for reg in regs.values():
+        assert not any(getattr(c, "placeholder", False) for c in reg.module_dict.values())
+
+    # ---- the literal config dicts (copied as data)
+    assigner = regs["BBOX_ASSIGNERS"].build(dict(
+        type='HungarianAssigner',
+        cls_cost=dict(type='FocalLossCost', weight=2.0),
+        reg_cost=dict(type='BBoxL1Cost', weight=5.0, box_format='xywh'),
+        iou_cost=dict(type='IoUCost', iou_mode='giou', weight=2.0)))
+    assert isinstance(assigner, s.HungarianAssigner) and assigner.reg_cost.box_format == "xywh" and assigner.iou_cost.weight == 2.0
+    assigner1 = regs["BBOX_ASSIGNERS"].build(dict(type='O2MAssigner'))
+    assert isinstance(assigner1, s.O2MAssigner) and assigner1.candidate_topk == 13
+    for cfg, attr in ((dict(type='FocalLossCost', weight=2.0), "alpha"), (dict(type='BBoxL1Cost', weight=5.0, box_format='xywh'),
+                      "box_format"), (dict(type='IoUCost', iou_mode='giou', weight=2.0), "iou_mode")):
+        c = regs["MATCH_COST"].build(cfg)
+        assert c.weight == cfg["weight"] and hasattr(c, attr) and callable(c)
+    loss = regs["LOSSES"].build(dict(type='TaskAlignedFocalLoss', use_sigmoid=True, gamma=2.0, loss_weight=2.0))
+    assert isinstance(loss, torch.nn.Module) and (loss.gamma, loss.loss_weight, loss.use_sigmoid) == (2.0, 2.0, True)
+    hook = regs["HOOKS"].build(dict(type="MeanTeacher", momentum=0.999, interval=1, warm_up=0))
+    assert isinstance(hook, s.MeanTeacher) and (hook.momentum, hook.interval, hook.warm_up) == (0.999, 1, 0)
+    from semi_detr_amd.dp import FlatDDP
+    assert regs["MODULE_WRAPPERS"].module_dict["FlatDDP"] is FlatDDP
+    # mmcv's is_module_wrapper(): isinstance(module, tuple(MODULE_WRAPPERS.module_dict.values()))
+    wrapped = FlatDDP(torch.nn.Linear(2, 2))
+    assert isinstance(wrapped, tuple(regs["MODULE_WRAPPERS"].module_dict.values())) and hasattr(wrapped, "module")

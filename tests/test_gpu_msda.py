@@ -187,6 +187,24 @@ def test_gradcheck_like_reference_test_py(D):
     assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, ls, loc, attn, 2))
 
 
+@pytest.mark.parametrize("D", [1025, 2048, 3096])
+def test_gradcheck_wide_channels_like_reference_test_py(D):
+    """ops/test.py:85-86 also runs check_gradient_numerical for 1025, 2048 and 3096 channels (the CUDA op's multi-block
+    reduction branches).  Same fp64 gradcheck through MSDeformAttnFunction on a pyramid small enough that the numerical
+    Jacobian (2 evaluations per input element) stays cheap."""
+    from semi_detr_amd import MSDeformAttnFunction
+    torch.manual_seed(D)
+    N, M, Lq, L, P = 1, 1, 2, 2, 2
+    shapes = torch.as_tensor([(2, 2), (1, 1)], dtype=torch.long).cuda()
+    ls = _level_start(shapes)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = (torch.rand(N, S, M, D).cuda() * 0.01).double().requires_grad_(True)
+    loc = torch.rand(N, Lq, M, L, P, 2).cuda().double().requires_grad_(True)
+    attn = torch.rand(N, Lq, M, L, P).cuda() + 1e-5
+    attn = (attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+    assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, ls, loc, attn, 2))
+
+
 def test_reference_test_py_forward_checks():
     """check_forward_equal_with_pytorch_{double,float} of ops/test.py:31-60, with the oracle in the role of
     ms_deform_attn_core_pytorch (itself pinned to it by the fixtures)."""

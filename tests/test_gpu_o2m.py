@@ -35,6 +35,35 @@ def test_o2m_assign_matches_reference_fixture(name):
     np.testing.assert_allclose(res.assign_metrics.cpu().numpy(), g["assign_metrics"], rtol=5e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("name", list(O2M["names"]))
+@pytest.mark.parametrize("tag,kw", [("t1", dict(teacher_assign=True)), ("tk", dict(teacher_assign=True, multiple_pos=True))])
+def test_o2m_teacher_options_match_reference_fixture(name, tag, kw):
+    """The teacher's two options of O2MAssigner.assign (o2m_assigner.py:115-133): best-aligned candidate only, and the
+    dynamic-k `multiple_pos` branch -- outputs of the reference's own assign()."""
+    from semi_detr_amd import O2MAssigner
+    g = case(name)
+    ih, iw = (int(v) for v in g["img_hw"])
+    res = O2MAssigner().assign(_t(g["bbox_pred"]), _t(g["cls_prob"]), _t(g["gt_bboxes"]), _t(g["gt_labels"]),
+                               dict(img_shape=(ih, iw, 3)), **kw)
+    np.testing.assert_array_equal(res.gt_inds.cpu().numpy(), g[f"{tag}_gt_inds"])
+    np.testing.assert_array_equal(res.labels.cpu().numpy(), g[f"{tag}_labels"])
+    np.testing.assert_allclose(res.max_overlaps.cpu().numpy(), g[f"{tag}_max_overlaps"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(res.assign_metrics.cpu().numpy(), g[f"{tag}_assign_metrics"], rtol=5e-6, atol=1e-9)
+    # and bit for bit against the oracle on a random problem with many zero-metric candidates (dynamic k keeps them)
+    rng = np.random.default_rng(len(name))
+    Q, C, G = 333, 6, 9
+    gt = np.concatenate([rng.random((G, 2)) * 300, rng.random((G, 2)) * 200 + 320], -1).astype(np.float32)
+    bp = np.concatenate([rng.random((Q, 2)), rng.random((Q, 2)) * 0.5 + 0.1], -1).astype(np.float32)
+    prob = (rng.random((Q, C)) * (rng.random((Q, C)) > 0.5)).astype(np.float32)
+    gl = rng.integers(0, C, G)
+    r2 = O2MAssigner(candidate_topk=7).assign(_t(bp), _t(prob), _t(gt), _t(gl), dict(img_shape=(480, 640, 3)), **kw)
+    okw = dict(topk=1) if tag == "t1" else dict(topk=7, dynamic_k=True)
+    gi, lab, mo, am = oracle.o2m_assign(bp, prob, gt, gl, 640, 480, **okw)
+    np.testing.assert_array_equal(r2.gt_inds.cpu().numpy(), gi)
+    np.testing.assert_array_equal(r2.max_overlaps.cpu().numpy(), mo)
+    np.testing.assert_array_equal(r2.assign_metrics.cpu().numpy(), am)
+
+
 def test_o2m_batch_targets_match_reference_fixture_and_oracle():
     """All fixture cases with the same (Q, C) cannot be stacked (sizes differ), so: the DINO case replicated as a
     7-layer x 3-image batch with per-problem ground truths taken from different fixtures' boxes."""

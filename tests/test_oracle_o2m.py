@@ -31,6 +31,20 @@ def test_o2m_oracle_matches_reference_fixture(name):
     np.testing.assert_allclose(nm, g["norm_metrics"], rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize("name", list(O2M["names"]))
+@pytest.mark.parametrize("tag,kw", [("t1", dict(topk=1)), ("tk", dict(topk=13, dynamic_k=True))])
+def test_o2m_oracle_teacher_options_match_reference_fixture(name, tag, kw):
+    """teacher_assign (best-aligned candidate only, o2m_assigner.py:115-119) and teacher_assign + multiple_pos (dynamic k,
+    :125-133), both produced by the reference's own O2MAssigner.assign."""
+    g = case(name)
+    ih, iw = g["img_hw"]
+    gi, lab, mo, am = oracle.o2m_assign(g["bbox_pred"], g["cls_prob"], g["gt_bboxes"], g["gt_labels"], iw, ih, **kw)
+    np.testing.assert_array_equal(gi, g[f"{tag}_gt_inds"])
+    np.testing.assert_array_equal(lab, g[f"{tag}_labels"])
+    np.testing.assert_allclose(mo, g[f"{tag}_max_overlaps"], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(am, g[f"{tag}_assign_metrics"], rtol=5e-6, atol=1e-9)
+
+
 def test_o2m_fixture_is_not_trivial():
     g = case("dup_gt")
     # overlapping ground truths: some query is a top-13 candidate of two gts and goes to the one with the larger IoU
