@@ -120,32 +120,45 @@ def test_encoder_bs4_wide_offsets_vs_oracle():
 
 
 def test_encoder_five_levels_full_size_vs_oracle():
-    """The COCO-Full recipe's pyramid (five feature levels, S = 22 300, BASELINE.json configs[3]) as ENCODER self-attention:
-    L * P = 20, so the forward takes the patch kernel with a runtime sample loop, the backward the generic-loop gather + the
-    region-owned scatter with five sampling levels.  N = 2, every element against the oracle."""
+    """The COCO-Full recipe's pyramid (five feature levels, S = 22 300, BASELINE.json configs[4]) as ENCODER self-attention AT THE
+    RECIPE'S BATCH (4 images per forward, detr_ssod_dino_detr_r50_coco_full_240k.py:6,24): L * P = 20, so the forward takes the
+    patch kernel with a runtime sample loop, the backward the gather unrolled for 20 samples (it clears grad_value as a side
+    job) + the region-owned scatter with five sampling levels.  Every element against the oracle; reference contract and fused
+    prologue / epilogue."""
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd  # noqa: F401
-    N, levels = 2, LEVELS + [(7, 11)]
+    N, levels = 4, LEVELS + [(7, 11)]
     value, shp, ref, off, logits, gout = _encoder_case(N, levels, 2.0, 13)
     loc, attn = _prologue_np(ref, off, logits, shp, P)
     o_out = oracle.msda_forward(value, shp, loc, attn)
-    o_gv, o_gl, o_ga = oracle.msda_backward(value, shp, loc, attn, gout)
+    o_gv, o_gl, o_ga = oracle.msda_backward(value, shp, loc, attn, gout, parallel=True)
     tsh = _t(shp)
     tls = _starts(tsh)
     out = MSDA.ms_deform_attn_forward(_t(value), tsh, tls, _t(loc), _t(attn), 64)
     gv, gl, ga = MSDA.ms_deform_attn_backward(_t(value), tsh, tls, _t(loc), _t(attn), _t(gout), 64)
     torch.cuda.synchronize()
+    if semi_detr_amd._lib.lib().semidetr_msda_last_kernels().decode().startswith("msda_bwd_gather_d32+"):
+        pass      # default dispatch: no memset in front -- the unrolled 20-sample gather cleared grad_value
     _check(out.cpu().numpy(), gv.cpu().numpy(), o_out, o_gv)
     np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
     np.testing.assert_allclose(gl.cpu().numpy(), o_gl, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gl).max())))
-    # the fused prologue / epilogue on the same inputs
+    # the fused prologue / epilogue on the same inputs, incl. its two small gradients
     out2 = MSDA.ms_deform_attn_fused_forward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits))
-    gv2, _, _ = MSDA.ms_deform_attn_fused_backward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits), _t(gout))
+    gv2, goff, glog = MSDA.ms_deform_attn_fused_backward(_t(value), tsh, tls, _t(ref), _t(off), _t(logits), _t(gout))
     torch.cuda.synchronize()
     _check(out2.cpu().numpy(), gv2.cpu().numpy(), o_out, o_gv)
+    L = len(levels)
+    scale = 1.0 / np.stack([shp[:, 1], shp[:, 0]], -1).astype(np.float64)[None, None, None, :, None, :]
+    want_off = (o_gl.astype(np.float64) * scale).astype(np.float32)
+    a64, g64 = attn.astype(np.float64).reshape(N, -1, M, L * P), o_ga.astype(np.float64).reshape(N, -1, M, L * P)
+    want_log = (a64 * (g64 - (a64 * g64).sum(-1, keepdims=True))).astype(np.float32)
+    ok = ~kink_mask(loc, shp)
+    np.testing.assert_allclose(goff.cpu().numpy()[ok], want_off[ok], rtol=0, atol=1e-4 * max(1.0, float(np.abs(want_off).max())))
+    np.testing.assert_allclose(glog.cpu().numpy(), want_log, rtol=0, atol=2e-5)
 
 
 @pytest.mark.parametrize("name,levels,N,Lq", [("five_level_bs2_Lq900", LEVELS + [(7, 11)], 2, 900),
+                                               ("five_level_bs4_Lq1100", LEVELS + [(7, 11)], 4, 1100),      # COCO-Full decoder
                                                ("decoder_bs4_Lq1100", LEVELS, 4, 1100)])
 def test_decoder_full_size_vs_oracle(name, levels, N, Lq):
     """bench.py's `five_level_bs2_Lq900` secondary shape (S = 22 300) and the bs-4 decoder launch with de-noising

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Measure the HBM-side traffic of the MSDA launches bench.py times and write profiles/r02_pmc_traffic.json.
+"""Measure the HBM-side traffic of the MSDA launches bench.py times and write profiles/r03_pmc_traffic.json.
 
 Run on the GPU box:   python tools/measure_traffic.py
 For each event group of the bench step (encoder / decoder, forward / backward, the batch sizes of the step) it runs
@@ -32,6 +32,9 @@ GROUPS = [  # bench group name, probe arguments
     ("msda_bwd_dec_bs1_Lq1100", ["--shape", "dec", "--bs", "1", "--lq", "1100", "--dir", "bwd"]),
     ("msda_fwd_micro_bs2_Lq300", ["--shape", "micro", "--bs", "2", "--dir", "fwd"]),
     ("msda_bwd_micro_bs2_Lq300", ["--shape", "micro", "--bs", "2", "--dir", "bwd"]),
+    # the same shape with 8 input sets rotated (> 256 MB: nothing is Infinity-Cache resident), as bench.py's cold micro-benchmark
+    ("msda_fwd_micro_bs2_Lq300_cold", ["--shape", "micro", "--bs", "2", "--dir", "fwd", "--cold", "8", "--iters", "16"]),
+    ("msda_bwd_micro_bs2_Lq300_cold", ["--shape", "micro", "--bs", "2", "--dir", "bwd", "--cold", "8", "--iters", "16"]),
 ]
 
 
@@ -51,8 +54,8 @@ def run_pass(counter, args, tag):
     d = os.path.join(OUT, tag + "_" + counter)
     shutil.rmtree(d, ignore_errors=True)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "tools", "msda_probe.py"), "--iters", "3", "--print-kernels"] + args
-    env = dict(os.environ, TMPDIR="/tmp")
+           sys.executable, os.path.join(ROOT, "tools", "msda_probe.py"), "--iters", "3", "--print-kernels"] + args      # a later --iters wins
+    env = dict(os.environ, TMPDIR="/tmp", SEMIDETR_EXPERIMENTS="0")      # the PRODUCT library is what is measured
     p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     if p.returncode != 0:
         raise SystemExit("rocprofv3 failed for %s %s:\n%s" % (tag, counter, p.stderr[-2000:]))
@@ -89,7 +92,7 @@ def main():
             raise SystemExit("%s: msda kernels in the trace the library did not report: %r" % (group, stray))
         res[group] = {"kernels": rep_f, "per_kernel": kernels, "hbm_bytes_corrected": int(total)}
         print(group, rep_f, "%.1f MB" % (total / 1e6), flush=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r02_pmc_traffic.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r03_pmc_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
 
 

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--fvariant", type=int, default=None)
     ap.add_argument("--sigma", type=float, default=2.0, help="encoder sample spread in pixels")
     ap.add_argument("--print-kernels", action="store_true", help="print what the library says it launched (KERNELS=...)")
+    ap.add_argument("--cold", type=int, default=1, help="rotate this many distinct input sets (8 x 47 MB > the Infinity Cache)")
     a = ap.parse_args()
     import semi_detr_amd as sda
     import MultiScaleDeformableAttention as MSDA
@@ -48,11 +49,25 @@ def main():
     attn = torch.rand(n, lq, M, L, P, device=dev) + 1e-5
     attn = attn / attn.sum((-1, -2), keepdim=True)
     gout = torch.rand(n, lq, M * D, device=dev)
+    sets = [(value, loc, attn, gout)]
+    for _ in range(a.cold - 1):
+        sets.append((torch.rand_like(value) * 0.01, loc.clone(), attn.clone(), gout.clone()))
+    turn = [0]
+
+    def pick():
+        turn[0] += 1
+        return sets[turn[0] % len(sets)]
     runs = []
     if a.dir in ("fwd", "both"):
-        runs.append(("fwd", lambda: MSDA.ms_deform_attn_forward(value, shapes, starts, loc, attn, 64), False))
+        def f():
+            v, lo, at, _ = pick()
+            MSDA.ms_deform_attn_forward(v, shapes, starts, lo, at, 64)
+        runs.append(("fwd", f, False))
     if a.dir in ("bwd", "both"):
-        runs.append(("bwd", lambda: MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn, gout, 64), True))
+        def b_():
+            v, lo, at, go = pick()
+            MSDA.ms_deform_attn_backward(v, shapes, starts, lo, at, go, 64)
+        runs.append(("bwd", b_, True))
     for name, fn, bw in runs:
         for _ in range(3):
             fn()
