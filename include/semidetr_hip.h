@@ -98,19 +98,24 @@ int semidetr_msda_backward_f64(void *stream, const double *grad_out, const doubl
  *   reference_points  (batch, num_query, num_levels, ref_dim)       ref_dim 2 or 4
  *   sampling_offsets  (batch, num_query, num_heads, num_levels, num_point, 2)   raw Linear output
  *   attn_logits       (batch, num_query, num_heads, num_levels * num_point)     raw Linear output (pre-softmax)
+ *   padding_mask      (batch, spatial_size) bytes, nonzero = padded pixel, or NULL: `value.masked_fill(mask[..., None], 0)`
+ *                     (ms_deform_attn.py:95-96) folded in -- a corner on a padded pixel reads as zero and receives no
+ *                     gradient, so `value` is passed UNMASKED and grad_value comes back with zero rows there.
  *   grad_sampling_offsets / grad_attn_logits: same shapes, every element written.
  * (The gradient w.r.t. reference_points, when a caller needs it, follows from grad_sampling_offsets on the
  *  host side; the reference detaches reference points between decoder layers, transformer.py:1033.)
  * ------------------------------------------------------------------------------------------- */
 int semidetr_msda_fused_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                                     const int64_t *level_start, const float *reference_points, int ref_dim,
-                                    const float *sampling_offsets, const float *attn_logits, int batch,
+                                    const float *sampling_offsets, const float *attn_logits,
+                                    const unsigned char *padding_mask, int batch,
                                     int spatial_size, int num_heads, int channels, int num_levels,
                                     int num_query, int num_point, int flags, float *out);
 int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const float *value,
                                      const int64_t *spatial_shapes, const int64_t *level_start,
                                      const float *reference_points, int ref_dim,
-                                     const float *sampling_offsets, const float *attn_logits, int batch,
+                                     const float *sampling_offsets, const float *attn_logits,
+                                     const unsigned char *padding_mask, int batch,
                                      int spatial_size, int num_heads, int channels, int num_levels,
                                      int num_query, int num_point, int flags, float *grad_value,
                                      float *grad_sampling_offsets, float *grad_attn_logits);

@@ -36,8 +36,8 @@ SIGNATURES = {
     "semidetr_msda_forward_f64": (c_int, _MSDA_FWD),
     "semidetr_msda_backward_f32": (c_int, _MSDA_BWD_F32),
     "semidetr_msda_backward_f64": (c_int, _MSDA_BWD),
-    "semidetr_msda_fused_forward_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 2 + [c_int] * 8 + [c_void_p]),
-    "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 2 + [c_int] * 8 + [c_void_p] * 3),
+    "semidetr_msda_fused_forward_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
+    "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 3 + [c_int] * 8 + [c_void_p] * 3),
     "semidetr_msda_last_kernels": (ctypes.c_char_p, []),
     "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
     "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),

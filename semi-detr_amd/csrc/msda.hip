@@ -586,8 +586,8 @@ static int check_fused(const void *value, const void *shapes, const void *starts
 extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                                                const int64_t *level_start, const float *reference_points,
                                                int ref_dim, const float *sampling_offsets,
-                                               const float *attn_logits, int batch, int spatial_size,
-                                               int num_heads, int channels, int num_levels, int num_query,
+                                               const float *attn_logits, const unsigned char *padding_mask, int batch,
+                                               int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                                                int num_point, int flags, float *out)
 {
     if (int rc = check_fused(value, spatial_shapes, level_start, reference_points, ref_dim, sampling_offsets,
@@ -595,7 +595,9 @@ extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value,
         return rc;
     SEMIDETR_REQUIRE(out && ((uintptr_t)out & 15) == 0, SEMIDETR_E_BADARG, "msda_fused_forward: bad output pointer");
     const RawIO io = {reference_points, sampling_offsets, attn_logits, nullptr, nullptr, ref_dim, num_heads,
-                      num_levels};
+                      num_levels, padding_mask, spatial_size};
+    SEMIDETR_REQUIRE(!padding_mask || SEMIDETR_FWD_VARIANT == 0, SEMIDETR_E_BADARG,
+                     "msda_fused_forward: the experimental kernel variants do not take a padding mask");
     return dispatch_fast_forward(semidetr::as_stream(stream), value, spatial_shapes, level_start, io, batch,
                                  spatial_size, num_heads, num_levels, num_query, num_point, flags, out);
 }
@@ -603,7 +605,8 @@ extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value,
 extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const float *value,
                                                 const int64_t *spatial_shapes, const int64_t *level_start,
                                                 const float *reference_points, int ref_dim,
-                                                const float *sampling_offsets, const float *attn_logits, int batch,
+                                                const float *sampling_offsets, const float *attn_logits,
+                                                const unsigned char *padding_mask, int batch,
                                                 int spatial_size, int num_heads, int channels, int num_levels,
                                                 int num_query, int num_point, int flags, float *grad_value,
                                                 float *grad_sampling_offsets, float *grad_attn_logits)
@@ -616,7 +619,9 @@ extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_
     SEMIDETR_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_value | (uintptr_t)grad_sampling_offsets) & 15) == 0,
                      SEMIDETR_E_BADARG, "msda_fused_backward: pointers must be 16-byte aligned");
     const RawIO io = {reference_points, sampling_offsets, attn_logits, grad_sampling_offsets, grad_attn_logits,
-                      ref_dim, num_heads, num_levels};
+                      ref_dim, num_heads, num_levels, padding_mask, spatial_size};
+    SEMIDETR_REQUIRE(!padding_mask || SEMIDETR_BWD_VARIANT == 0, SEMIDETR_E_BADARG,
+                     "msda_fused_backward: the experimental kernel variants do not take a padding mask");
     return dispatch_fast_backward(semidetr::as_stream(stream), grad_out, value, spatial_shapes, level_start, io, batch,
                                   spatial_size, num_heads, num_levels, num_query, num_point, flags, grad_value);
 }

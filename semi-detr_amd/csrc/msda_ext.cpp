@@ -232,9 +232,21 @@ Dims fused_dims(const at::Tensor &value, const at::Tensor &shapes, const at::Ten
     return d;
 }
 
+// input_padding_mask (N, S) bool / uint8, True = padding, or None: handed to the kernels as bytes
+const unsigned char *mask_ptr(const c10::optional<at::Tensor> &mask, const at::Tensor &value, const Dims &d)
+{
+    if (!mask.has_value() || !mask->defined()) return nullptr;
+    const at::Tensor &m = *mask;
+    TORCH_CHECK(m.is_cuda() && m.device() == value.device() && m.is_contiguous() && m.dim() == 2 && m.size(0) == d.N &&
+                    m.size(1) == d.S && (m.scalar_type() == at::kBool || m.scalar_type() == at::kByte),
+                "ms_deform_attn_fused: padding_mask must be a contiguous (N, S) bool / uint8 tensor on value's device");
+    return static_cast<const unsigned char *>(m.data_ptr());
+}
+
 at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tensor &spatial_shapes,
                                         const at::Tensor &level_start_index, const at::Tensor &reference_points,
-                                        const at::Tensor &sampling_offsets, const at::Tensor &attn_logits)
+                                        const at::Tensor &sampling_offsets, const at::Tensor &attn_logits,
+                                        const c10::optional<at::Tensor> &padding_mask)
 {
     const Dims d = fused_dims(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits);
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
@@ -243,7 +255,7 @@ at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tenso
     const int rc = semidetr_msda_fused_forward_f32(
         stream_of(value), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(),
         reference_points.data_ptr<float>(), (int)reference_points.size(-1), sampling_offsets.data_ptr<float>(),
-        attn_logits.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
+        attn_logits.data_ptr<float>(), mask_ptr(padding_mask, value, d), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
         self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), out.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_fused_forward");
     return out;
@@ -253,7 +265,8 @@ std::vector<at::Tensor> ms_deform_attn_fused_backward(const at::Tensor &value, c
                                                       const at::Tensor &level_start_index,
                                                       const at::Tensor &reference_points,
                                                       const at::Tensor &sampling_offsets, const at::Tensor &attn_logits,
-                                                      const at::Tensor &grad_output)
+                                                      const at::Tensor &grad_output,
+                                                      const c10::optional<at::Tensor> &padding_mask)
 {
     const Dims d = fused_dims(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits);
     TORCH_CHECK(grad_output.is_contiguous() && grad_output.numel() == (int64_t)d.N * d.Lq * d.M * d.D &&
@@ -265,8 +278,8 @@ std::vector<at::Tensor> ms_deform_attn_fused_backward(const at::Tensor &value, c
     const int rc = semidetr_msda_fused_backward_f32(
         stream_of(value), grad_output.data_ptr<float>(), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(),
         level_start_index.data_ptr<int64_t>(), reference_points.data_ptr<float>(), (int)reference_points.size(-1),
-        sampling_offsets.data_ptr<float>(), attn_logits.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
-        self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), gv.data_ptr<float>(), go.data_ptr<float>(),
+        sampling_offsets.data_ptr<float>(), attn_logits.data_ptr<float>(), mask_ptr(padding_mask, value, d), d.N, d.S, d.M, d.D,
+        d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), gv.data_ptr<float>(), go.data_ptr<float>(),
         gl.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_fused_backward");
     return {gv, go, gl};
@@ -281,8 +294,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ms_deform_attn_forward", &ms_deform_attn_forward, "ms_deform_attn_forward");
     m.def("ms_deform_attn_backward", &ms_deform_attn_backward, "ms_deform_attn_backward");
     // additions
-    m.def("ms_deform_attn_fused_forward", &ms_deform_attn_fused_forward);
-    m.def("ms_deform_attn_fused_backward", &ms_deform_attn_fused_backward);
+    m.def("ms_deform_attn_fused_forward", &ms_deform_attn_fused_forward, py::arg("value"), py::arg("spatial_shapes"),
+          py::arg("level_start_index"), py::arg("reference_points"), py::arg("sampling_offsets"), py::arg("attn_logits"),
+          py::arg("padding_mask") = py::none());
+    m.def("ms_deform_attn_fused_backward", &ms_deform_attn_fused_backward, py::arg("value"), py::arg("spatial_shapes"),
+          py::arg("level_start_index"), py::arg("reference_points"), py::arg("sampling_offsets"), py::arg("attn_logits"),
+          py::arg("grad_output"), py::arg("padding_mask") = py::none());
     m.def("fused_supported", &fused_supported);
     m.def("pyramid_check", &pyramid_check,
           "bit 0: sum(H*W) == S; bit 1: level_start_index tiles [0, S) exactly.  Cached per tensor pair / version.");

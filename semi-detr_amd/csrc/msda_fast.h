@@ -16,6 +16,8 @@ struct LocAttnIO {
     const float *loc, *attn;
     float *gloc, *gattn;
     static constexpr bool kSoftmax = false;      // attn already holds probabilities
+    __device__ __forceinline__ bool masked(int n, int pixel) const { (void)n; (void)pixel; return false; }
+    __device__ __forceinline__ bool has_mask() const { return false; }
     __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
@@ -42,22 +44,35 @@ struct LocAttnIO {
     }
 };
 
+__device__ __forceinline__ float rawio_group_sum(float x, int LP);      // = lp_group_sum, defined below (needs dpp_mov)
+
 struct RawIO {
     const float *ref, *off, *logit;      // (N,Lq,L,ref_dim), (N,Lq,M,L,P,2), (N,Lq,M,L*P)
     float *goff, *glogit;
     int ref_dim, M, L;
+    // input_padding_mask of MSDeformAttn.forward (ms_deform_attn.py:95-96: value.masked_fill(mask[..., None], 0)), folded in:
+    // (N, S) bytes, nonzero = padding, or null.  A corner on a masked pixel is treated like a corner outside its level -- it
+    // reads as zero and receives no gradient -- so the masked copy of `value` (one 91 MB read + write per encoder layer call
+    // at bs 4) and the masking of grad_value never happen.
+    const unsigned char *mask;
+    int S;
     static constexpr bool kSoftmax = true;       // load_w returns a raw logit; the kernel normalises the row
+    __device__ __forceinline__ bool masked(int n, int pixel) const { return mask[(int64_t)n * S + pixel] != 0; }
+    __device__ __forceinline__ bool has_mask() const { return mask != nullptr; }
     __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
         const float *rp = ref + (nq * L + l) * ref_dim;
         const float2 o = *reinterpret_cast<const float2 *>(off + (row * LP + k) * 2);
+        // x / W as x * rcp(W) (v_rcp_f32, 1 ulp): a true division is ~10 instructions per coordinate, and the location is
+        // compared with the reference's to 1e-4, not bit for bit (the oracle-exact path is LocAttnIO)
         if (ref_dim == 2) {          // ms_deform_attn.py:102-105
-            x = rp[0] + o.x / (float)W;
-            y = rp[1] + o.y / (float)H;
+            x = rp[0] + o.x * __frcp_rn((float)W);
+            y = rp[1] + o.y * __frcp_rn((float)H);
         } else {                     // ms_deform_attn.py:106-108
-            x = rp[0] + o.x / (float)P * rp[2] * 0.5f;
-            y = rp[1] + o.y / (float)P * rp[3] * 0.5f;
+            const float ip = __frcp_rn((float)P);
+            x = rp[0] + o.x * ip * rp[2] * 0.5f;
+            y = rp[1] + o.y * ip * rp[3] * 0.5f;
         }
     }
     __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return logit[row * LP + k]; }
@@ -67,7 +82,7 @@ struct RawIO {
     {
         float dot = res.w * res.x;               // softmax backward: a_k * (g_k - sum_j a_j g_j)
         if ((LP & (LP - 1)) == 0 && LP <= 64) {
-            for (int d = 1; d < LP; d <<= 1) dot += __shfl_xor(dot, d, 64);
+            dot = rawio_group_sum(dot, LP);
         } else {                                 // generic LP: every thread re-reads the row (rare)
             dot = 0.f;
             for (int j = 0; j < LP; ++j) dot += row_res[j].w * row_res[j].x;
@@ -81,14 +96,28 @@ struct RawIO {
         glogit[row * LP + k] = res.w * (res.x - dot);
         float2 g;
         if (ref_dim == 2) {
-            g = make_float2(res.y / (float)W, res.z / (float)H);
+            g = make_float2(res.y * __frcp_rn((float)W), res.z * __frcp_rn((float)H));
         } else {
             const float *rp = ref + (nq * L + l) * ref_dim;
-            g = make_float2(res.y * 0.5f * rp[2] / (float)P, res.z * 0.5f * rp[3] / (float)P);
+            const float ip = __frcp_rn((float)P);
+            g = make_float2(res.y * 0.5f * rp[2] * ip, res.z * 0.5f * rp[3] * ip);
         }
         *reinterpret_cast<float2 *>(goff + (row * LP + k) * 2) = g;
     }
 };
+
+// Padding mask for the kernels that LOAD / scatter through byte offsets (forward, strips backward, gather): corners whose
+// pixel is masked become kOob.  (x, y) -> top-left pixel exactly as sample_setup_oob derives it.
+template <typename IO>
+__device__ __forceinline__ void mask_corners_oob(const IO &io, int n, float x, float y, int H, int W, int st, unsigned (&off)[4])
+{
+    if (!io.has_mask()) return;
+    const int h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f)), w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
+    const int pix = st + h0 * W + w0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (off[c] != kOob && io.masked(n, pix + (c & 1) + (c >> 1) * W)) off[c] = kOob;
+}
 
 // ---------------------------------------------------------------------------------------------
 // fast path: fp32, D == 32.  8 lanes x float4 per 128-byte value row.
@@ -121,24 +150,83 @@ __device__ __forceinline__ float group8_sum(float x)
 // Softmax over the L*P logits of one (n, q, m) row (ms_deform_attn.py:101), evaluated cooperatively by the LP
 // consecutive threads that own the row's samples: one expf per sample, max / sum by xor-shuffles when LP is a
 // power of two <= 64 (the DINO case LP = 16 is one DPP row); any other LP falls back to a per-thread loop.
+__device__ __forceinline__ bool lp_shuffles(int LP) { return (LP & (LP - 1)) == 0 && LP <= 64; }
+// sum / max over a lane-aligned group of LP threads (LP a power of two <= 64); every lane of the group gets the result
+__device__ __forceinline__ float lp_group_sum(float x, int LP)
+{
+    if (LP >= 2) x += dpp_mov<0xB1>(x);      // quad_perm [1,0,3,2]
+    if (LP >= 4) x += dpp_mov<0x4E>(x);      // quad_perm [2,3,0,1]
+    if (LP >= 8) x += dpp_mov<0x141>(x);     // row_half_mirror
+    if (LP >= 16) x += dpp_mov<0x140>(x);    // row_mirror
+    if (LP >= 32) x += __shfl_xor(x, 16, 64);
+    if (LP >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+}
+__device__ __forceinline__ float rawio_group_sum(float x, int LP) { return lp_group_sum(x, LP); }
+__device__ __forceinline__ float lp_group_max(float x, int LP)
+{
+    if (LP >= 2) x = fmaxf(x, dpp_mov<0xB1>(x));
+    if (LP >= 4) x = fmaxf(x, dpp_mov<0x4E>(x));
+    if (LP >= 8) x = fmaxf(x, dpp_mov<0x141>(x));
+    if (LP >= 16) x = fmaxf(x, dpp_mov<0x140>(x));
+    if (LP >= 32) x = fmaxf(x, __shfl_xor(x, 16, 64));
+    if (LP >= 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
+    return x;
+}
+
 template <typename IO>
 __device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, int k, float raw)
 {
     if (!IO::kSoftmax) return raw;
-    if ((LP & (LP - 1)) == 0 && LP <= 64) {
-        float mx = raw;
-        for (int d = 1; d < LP; d <<= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-        const float e = expf(raw - mx);
-        float sum = e;
-        for (int d = 1; d < LP; d <<= 1) sum += __shfl_xor(sum, d, 64);
-        return e / sum;
+    if (lp_shuffles(LP)) {
+        // reductions over the LP lane-aligned threads of the row: DPP inside a 16-lane row (quad xor 1, quad xor 2, half
+        // mirror, row mirror -- VALU-rate), shuffles (LDS crossbar, ~100 clk each in a dependent chain) only beyond 16.
+        // As eight __shfl_xor per softmax the fused prologue ran 14 % behind the reference-contract kernels.
+        const float mx = lp_group_max(raw, LP);
+        const float e = __expf(raw - mx);
+        return e * __frcp_rn(lp_group_sum(e, LP));
     }
     float mx = raw;
     for (int j = 0; j < LP; ++j) mx = fmaxf(mx, io.load_w(row, LP, j));
     float sum = 0.f;
-    for (int j = 0; j < LP; ++j) sum += expf(io.load_w(row, LP, j) - mx);
+    for (int j = 0; j < LP; ++j) sum += __expf(io.load_w(row, LP, j) - mx);
     (void)k;
-    return expf(raw - mx) / sum;
+    return __expf(raw - mx) * __frcp_rn(sum);
+}
+
+// The same softmax for an L*P that is not a power of two (five levels x four points = 20: the COCO-Full recipe), where the
+// LP threads of a row do not line up with the wavefront's shuffle groups and the per-thread loop above costs LP loads + LP
+// exponentials PER SAMPLE (2.3x on the whole forward).  Eight threads per query row instead: thread j takes logits j, j + 8,
+// ..., the row maximum / sum are 3-step DPP reductions inside the octet, and the probabilities are parked in the .x of the
+// row's (not yet written) records; the kernel's record loop picks them up after ONE extra barrier.
+// rec: the float4 record array with LPP = LP + 1 entries per row; row_of(r) -> (n * Lq + q) * M + m or -1.
+template <typename IO, typename RowOf>
+__device__ __forceinline__ void softmax_rows_to_lds(const IO &io, int tid, int RPB, int LP, int LPP, float4 *rec, RowOf row_of)
+{
+    const int r = tid >> 3, j = tid & 7;
+    const int64_t row = r < RPB ? row_of(r) : -1;
+    float raw[8], mx = -__builtin_huge_valf();            // LP <= 64 (checked by the launcher for this path)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        raw[i] = -__builtin_huge_valf();
+        if (row >= 0 && j + 8 * i < LP) raw[i] = io.load_w(row, LP, j + 8 * i);
+        mx = fmaxf(mx, raw[i]);
+    }
+    mx = fmaxf(mx, dpp_mov<0xB1>(mx));
+    mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+    mx = fmaxf(mx, dpp_mov<0x141>(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        raw[i] = (row >= 0 && j + 8 * i < LP) ? __expf(raw[i] - mx) : 0.f;
+        sum += raw[i];
+    }
+    sum = group8_sum(sum);
+    const float inv = __frcp_rn(sum);
+    if (row >= 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (j + 8 * i < LP) rec[r * LPP + j + 8 * i].x = raw[i] * inv;
 }
 
 // Workgroup -> (n, query tile, m).  Consecutive workgroups take consecutive heads, and the head of a given slot is
@@ -225,6 +313,11 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     constexpr int PH = PATCH / 100, PW = PATCH % 100;
     static_assert(PATCH == 0 || (PH * PW == RPB && SPLIT == 1), "a patch holds exactly the workgroup's rows");
     Patch pt = {0, 0, 0, 0, 0};
+    // When L*P divides 256 a thread's samples s = tid, tid + 256, ... all have the same (level, point): its level's H, W,
+    // start (three dependent int64 global loads per sample otherwise, in front of the coordinate arithmetic) are fetched once
+    const bool fixed_k = (256 % LP) == 0;
+    const int lf = ((int)threadIdx.x % LP) / P;
+    const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
     // PATCH: tiles_per_image is only a sizing hint for the grid -- a workgroup takes patches slot, slot + hint,
     // ... until the pyramid is exhausted, so any hint >= 1 is correct (the level table is device memory).
     for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
@@ -236,6 +329,14 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     auto query_of = [&](int r) { return PATCH ? patch_query<PW ? PW : 1>(pt, r) : (t.q0 + r < Lq ? t.q0 + r : -1); };
 
     // ---- phase 1: sample records -------------------------------------------------------------
+    const bool sm_lds = IO::kSoftmax && !lp_shuffles(LP) && LP <= 64;      // see softmax_rows_to_lds
+    if (sm_lds) {
+        softmax_rows_to_lds(io, (int)threadIdx.x, RPB, LP, LPP, rec_w, [&](int r_) -> int64_t {
+            const int q_ = query_of(r_);
+            return q_ >= 0 ? ((int64_t)t.n * Lq + q_) * M + t.m : -1;
+        });
+        __syncthreads();
+    }
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
         const int q = query_of(r);
@@ -243,14 +344,16 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
         float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q >= 0) {
             const int l = k / P;
-            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
+            const int st = fixed_k ? stf : (int)starts[l];
             const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
             float x, y, lw, lh;
             io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
-            const float a = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            const float a = sm_lds ? rec_w[r * LPP + k].x : row_softmax(io, row, LP, k, io.load_w(row, LP, k));
             if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 w = make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw));
+                mask_corners_oob(io, t.n, x, y, H, W, st, off);
             }
         }
         rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
@@ -334,6 +437,13 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
         lev_h[threadIdx.x] = (float)shapes[2 * threadIdx.x];
         lev_w[threadIdx.x] = (float)shapes[2 * threadIdx.x + 1];
     }
+    const bool sm_lds = IO::kSoftmax && !lp_shuffles(LP) && LP <= 64;      // see softmax_rows_to_lds
+    if (sm_lds) {
+        softmax_rows_to_lds(io, (int)threadIdx.x, RPB, LP, LPP, rec_p, [&](int r_) -> int64_t {
+            return t.q0 + r_ < Lq ? ((int64_t)t.n * Lq + t.q0 + r_) * M + t.m : -1;
+        });
+        __syncthreads();
+    }
     for (int s = threadIdx.x; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
         const int q = t.q0 + r;
@@ -346,10 +456,11 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
             float x, y, lw, lh;
             io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
             // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
-            pr.z = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            pr.z = sm_lds ? rec_p[r * LPP + k].x : row_softmax(io, row, LP, k, io.load_w(row, LP, k));
             if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                 pr.x = lw;
                 pr.y = lh;
+                mask_corners_oob(io, t.n, x, y, H, W, st, off);
             }
         }
         rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
@@ -450,6 +561,10 @@ __device__ __forceinline__ void gather_body(
     constexpr int PH = PATCH / 100, PW = PATCH % 100;
     static_assert(PATCH == 0 || PH * PW == RPB, "a patch holds exactly the workgroup's rows");
     Patch pt = {0, 0, 0, 0, 0};
+    // level constants of this thread's sample slot, fetched once when L*P divides 256 (see msda_fwd_d32)
+    const bool fixed_k = (256 % LP) == 0;
+    const int lf = (tid % LP) / P;
+    const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
     // PATCH: tiles_per_image is a grid sizing hint; a workgroup takes patches slot, slot + hint, ... (see the forward)
     for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
     if (PATCH) {
@@ -463,6 +578,14 @@ __device__ __forceinline__ void gather_body(
     }
     const bool live = active && (!PATCH || pt.Hq != 0);
     auto query_of = [&](int rr_) { return !live ? -1 : (PATCH ? patch_query<PW ? PW : 1>(pt, rr_) : (t.q0 + rr_ < Lq ? t.q0 + rr_ : -1)); };
+    const bool sm_lds = IO::kSoftmax && !lp_shuffles(LP) && LP <= 64;      // see softmax_rows_to_lds
+    if (sm_lds) {
+        softmax_rows_to_lds(io, tid, RPB, LP, LPP, rec_p, [&](int r_) -> int64_t {
+            const int q_ = query_of(r_);
+            return q_ >= 0 ? ((int64_t)t.n * Lq + q_) * M + t.m : -1;
+        });
+        __syncthreads();
+    }
     for (int s = tid; s < RPB * LP; s += 256) {
         const int r = s / LP, k = s - r * LP;
         const int q = query_of(r);
@@ -470,15 +593,17 @@ __device__ __forceinline__ void gather_body(
         const int l = k / P;
         float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
         if (q >= 0) {
-            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+            const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
+            const int st = fixed_k ? stf : (int)starts[l];
             const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
             float x, y, lw, lh;
             io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
             // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
-            pr.z = row_softmax(io, row, LP, k, io.load_w(row, LP, k));
+            pr.z = sm_lds ? rec_p[r * LPP + k].x : row_softmax(io, row, LP, k, io.load_w(row, LP, k));
             if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                 pr.x = lw;
                 pr.y = lh;
+                mask_corners_oob(io, t.n, x, y, H, W, st, off);
             }
         }
         rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
@@ -1187,6 +1312,10 @@ __device__ __forceinline__ void lvl_scatter_body(
         int off[4];
         float lw, lh;
         if (sidx >= nsamp || !sample_setup(sx[sp], sy[sp], H, W, 0, 1, off, lw, lh)) continue;   // off = level-local pixel or -1
+        if (io.has_mask())
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+                if (off[ci] >= 0 && io.masked(n, st + off[ci])) off[ci] = -1;      // padded pixels receive no gradient
         const float a = sa[sp];
         const float hh = 1.f - lh, hwt = 1.f - lw;
         cw[sp][0] = hh * hwt * a; cw[sp][1] = hh * lw * a; cw[sp][2] = lh * hwt * a; cw[sp][3] = lh * lw * a;

@@ -190,6 +190,10 @@ __device__ __forceinline__ void reg_scatter_body(
                             if (IO::kSoftmax) a = expf(a - sm_max[sp]) * sm_inv[sp];
                             h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
                             w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
+                            if (io.has_mask())      // padded pixels receive no gradient (fused prologue, see RawIO)
+#pragma unroll
+                                for (int cidx = 0; cidx < 4; ++cidx)
+                                    if (off[cidx] >= 0 && io.masked(n, st + h0 * W + w0 + (cidx & 1) + (cidx >> 1) * W)) off[cidx] = -1;
                         }
                     }
                     const int wy = h0 - y0, wx = w0 - x0;

@@ -40,22 +40,27 @@ class MSDeformAttnFusedFunction(Function):
     """MSDeformAttn.forward between the Linear layers as ONE op: consumes the
     reference points, the raw sampling offsets and the raw attention logits; softmax, location arithmetic
     (detr_od/models/utils/ops/modules/ms_deform_attn.py:99-111) and their backward run inside the gfx950 kernels.
-    ``apply(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits)``."""
+    ``apply(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits[, padding_mask])``.
+    ``padding_mask`` (N, S) bool, True = padding: ``value.masked_fill(mask[..., None], 0)`` (ms_deform_attn.py:95-96) folded
+    into the kernels -- pass the UNMASKED value; its gradient comes back with zero rows at the padded pixels."""
 
     @staticmethod
-    def forward(ctx, value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits):
+    def forward(ctx, value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits,
+                padding_mask=None):
+        if padding_mask is not None:
+            padding_mask = padding_mask.contiguous()
         output = MSDA.ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points,
-                                                   sampling_offsets, attn_logits)
+                                                   sampling_offsets, attn_logits, padding_mask)
         ctx.save_for_backward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                              attn_logits)
+                              attn_logits, padding_mask)
         return output
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
-        value, shapes, starts, ref, off, logits = ctx.saved_tensors
+        value, shapes, starts, ref, off, logits, padding_mask = ctx.saved_tensors
         grad_value, grad_off, grad_logits = MSDA.ms_deform_attn_fused_backward(
-            value, shapes, starts, ref, off, logits, grad_output.contiguous())
+            value, shapes, starts, ref, off, logits, grad_output.contiguous(), padding_mask)
         grad_ref = None
         if ctx.needs_input_grad[3]:
             # d loc / d ref: the chain rule through the (elementwise) location arithmetic, from grad_off
@@ -68,4 +73,4 @@ class MSDeformAttnFusedFunction(Function):
                 scale = 0.5 * wh / P
                 grad_loc = torch.where(scale != 0, grad_off / scale, torch.zeros_like(grad_off))
                 grad_ref = torch.cat([grad_loc.sum((2, 4)), (grad_loc * off * (0.5 / P)).sum((2, 4))], -1)
-        return grad_value, None, None, grad_ref, grad_off, grad_logits
+        return grad_value, None, None, grad_ref, grad_off, grad_logits, None

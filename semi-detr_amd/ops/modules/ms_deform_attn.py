@@ -78,20 +78,21 @@ class MSDeformAttn(nn.Module):
         assert MSDA.pyramid_check(input_spatial_shapes, input_level_start_index, Len_in) & 1
         M, L, P = self.n_heads, self.n_levels, self.n_points
 
-        value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
-        value = value.view(N, Len_in, M, self.d_model // M)
+        value = self.value_proj(input_flatten).view(N, Len_in, M, self.d_model // M)
         offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
         logits = self.attention_weights(query).view(N, Len_q, M, L * P)
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead."
                              .format(reference_points.shape[-1]))
         if self.fuse_prologue and MSDA.fused_supported(value, reference_points, offsets, logits):
+            # the padding mask (ms_deform_attn.py:95-96) goes INTO the kernels: no masked copy of `value`, no masking of its
+            # gradient
             output = MSDeformAttnFusedFunction.apply(value.contiguous(), input_spatial_shapes,
                                                      input_level_start_index, reference_points.contiguous(),
-                                                     offsets.contiguous(), logits.contiguous())
+                                                     offsets.contiguous(), logits.contiguous(), input_padding_mask)
             return self.output_proj(output)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None, None], float(0))
         weights = F.softmax(logits, -1).view(N, Len_q, M, L, P)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
