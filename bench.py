@@ -97,15 +97,15 @@ class StudentParams(torch.nn.Module):
     """The student's parameter list (DINO-R50 + projector, ~60 M fp32) as a module FlatDDP can wrap, grouped by the
     order backward finishes them: heads, decoder, encoder, backbone."""
 
-    def __init__(self, dev):
+    def __init__(self, dev, scale=1):
         super().__init__()
-        sizes = dino_param_sizes()
+        sizes = [max(1, n // scale) for n in dino_param_sizes()]      # scale > 1: the CPU test of the bucket arithmetic
         nb = 3 + 9 * 16 + 3 * 4                        # ResNet-50 entries of dino_param_sizes()
         enc = 6 * 16
         dec = 6 * 22
         split = {"backbone": sizes[:nb], "encoder": sizes[nb:nb + enc], "decoder": sizes[nb + enc:nb + enc + dec],
                  "heads": sizes[nb + enc + dec:]}
-        extra = GRAD_ELEMS - sum(sizes)                # projector etc.: counted with the heads
+        extra = GRAD_ELEMS // scale - sum(sizes)       # projector etc.: counted with the heads
         if extra > 0:
             split["heads"] = split["heads"] + [extra]
         self.groups = {}
@@ -874,6 +874,7 @@ def main():
                 "per_step_all_reduce": coll_timed["all_reduce"] / args.steps, "per_step_other": coll_timed["other"] / args.steps,
                 "all_reduce_mb_per_step": coll_timed["all_reduce_bytes"] / args.steps / 1e6,
                 "backend": dist.get_backend(), "world_size": world,
+                "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
                 "nccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
                 "note": "buckets of 64 MiB over a 240 MB gradient arena = 4 all-reduces per step, issued in arena order on every "
                         "rank; the backbone's 60 % of the arena is marked ready only after the last MSDA backward launch, so "

@@ -74,28 +74,48 @@ class _EmaTable:
 
 
 _table_cache = {}
-_last = None            # (teacher Parameter objects, student Parameter objects, table, calls since full validation)
-_REVALIDATE_EVERY = 256
+_last = None            # [weakrefs to the teacher Parameters, weakrefs to the student Parameters, table, calls since full check]
+_REVALIDATE_EVERY = 64
+_SAMPLE_STRIDE = 8
+
+
+def _same_objects(refs, params):
+    return len(refs) == len(params) and all(r() is p for r, p in zip(refs, params))
 
 
 def ema_update_(teacher_params, student_params, momentum):
     """In place: teacher <- momentum * teacher + (1 - momentum) * student for two parameter lists.
 
-    The device-side pointer table is reused while the parameter lists are the same OBJECTS as in the previous call
-    (an identity scan, ~15 us for the 466 tensors of DINO-R50; rebuilding the (data_ptr, numel) key cost more host
-    time than the 98 us kernel).  The table keeps the tensors alive, so a stale entry can never point
-    at freed memory; a parameter re-pointed to new storage (`p.data = ...`) is caught by the full pointer
-    validation that still runs every 256th call and whenever the identity scan fails."""
+    The device-side pointer table is reused while the parameter lists are the same OBJECTS as in the previous call (an
+    identity scan through weak references, ~20 us for the 466 tensors of DINO-R50; rebuilding the (data_ptr, numel) key cost
+    more host time than the 98 us kernel).  A parameter re-pointed to new storage (``p.data = ...``,
+    ``module.to()``, FSDP-style flattening) keeps its identity, so every fast-path call also compares the storage address
+    of every 8th pair (and of the last one) with the table, and every 64th call re-validates all of them (255
+    silent steps were possible before).  The table keeps the tensors it points at alive, so even a stale entry never touches
+    freed memory; the references to the models themselves are weak -- a deleted model takes its table with it."""
     global _last
+    import weakref
     teacher_params, student_params = list(teacher_params), list(student_params)
-    if _last is not None and len(_last[0]) == len(teacher_params) and len(_last[1]) == len(student_params) \
-            and _last[3] < _REVALIDATE_EVERY and all(a is b for a, b in zip(_last[0], teacher_params)) \
-            and all(a is b for a, b in zip(_last[1], student_params)):
-        _last[3] += 1
-        _last[2].launch(momentum)
-        return
-    pairs = [(s.data, t.data) for s, t in zip(student_params, teacher_params)]
-    pairs = [(s, t) for s, t in pairs if s.numel() > 0]
+    if _last is not None:
+        tr, sr, table, calls = _last
+        if calls < _REVALIDATE_EVERY and _same_objects(tr, teacher_params) and _same_objects(sr, student_params):
+            tp, sp = table.key[0], table.key[1]
+            idx = table.live_index                       # positions of the non-empty pairs in the parameter lists
+            ok = True
+            for j in list(range(0, len(idx), _SAMPLE_STRIDE)) + ([len(idx) - 1] if idx else []):
+                i = idx[j]
+                if teacher_params[i].data_ptr() != tp[j] or student_params[i].data_ptr() != sp[j]:
+                    ok = False
+                    break
+            if ok:
+                _last[3] += 1
+                table.launch(momentum)
+                return
+        if any(r() is None for r in tr) or any(r() is None for r in sr):      # the models are gone: release their tables
+            _table_cache.clear()
+        _last = None
+    live = [i for i, (s, t) in enumerate(zip(student_params, teacher_params)) if s.numel() > 0]
+    pairs = [(student_params[i].data, teacher_params[i].data) for i in live]
     if not pairs:
         return
     key = _EmaTable.key_of(pairs)
@@ -105,7 +125,11 @@ def ema_update_(teacher_params, student_params, momentum):
             _table_cache.clear()
         table = _table_cache[key] = _EmaTable(pairs)
         table.keepalive = pairs
-    _last = [teacher_params, student_params, table, 0]
+    table.live_index = live
+    try:
+        _last = [[weakref.ref(p) for p in teacher_params], [weakref.ref(p) for p in student_params], table, 0]
+    except TypeError:           # plain tensors that cannot be weakly referenced: no fast path
+        _last = None
     table.launch(momentum)
 
 
@@ -155,10 +179,18 @@ class MeanTeacher(_HookBase):
         self.momentum_update(model, momentum)
 
     def after_train_iter(self, runner):
+        # the batched target assignment reports scipy's ValueError (NaN / infeasible costs) from a device status word without
+        # draining the stream; polled here so that it surfaces within the iteration that produced it
+        from . import targets
+        targets.check_deferred(block=False)
         curr_step = runner.iter
         if self.decay_intervals is None:
             return
         self.momentum = 1 - (1 - self.momentum) / self.decay_factor ** bisect_right(self.decay_intervals, curr_step)
+
+    def after_run(self, runner):
+        from . import targets
+        targets.check_deferred(block=True)       # nothing may stay unreported when training ends
 
     def momentum_update(self, model, momentum):
         students = [p for _, p in model.student.named_parameters()]

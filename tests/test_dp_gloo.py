@@ -282,3 +282,70 @@ def test_flat_ddp_single_process():
                 off = (p.grad.data_ptr() - net.arena.flat.data_ptr()) // 4
                 assert 0 <= off < net.arena.flat.numel()
         opt.step()
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py's N > 1 bookkeeping on CPU: the student's parameter list (scaled down 64x, buckets scaled alike) wrapped in
+# FlatDDP and driven through mark_ready / finish exactly as bench.Workload.step does -- a counting wrapper around
+# dist.all_reduce must see <= 4 bucket collectives per step and nothing else.
+# ---------------------------------------------------------------------------------------------------
+def _bench_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from semi_detr_amd import dp
+    dp.init_distributed(backend="gloo")
+    try:
+        scale = 64
+        student = bench.StudentParams(torch.device("cpu"), scale=scale)
+        ddp = dp.FlatDDP(student, broadcast_buffers=False, find_unused_parameters=False, bucket_bytes=(64 << 20) // scale)
+        assert abs(ddp.arena.numel - bench.GRAD_ELEMS // scale) < 1000
+        calls = {"all_reduce": 0, "elems": 0, "other": 0}
+        real_ar, real_ag, real_bc = dist.all_reduce, dist.all_gather, dist.broadcast
+
+        def counted(t, *a, **k):
+            calls["all_reduce"] += 1
+            calls["elems"] += t.numel()
+            return real_ar(t, *a, **k)
+
+        def other(fn):
+            def w(*a, **k):
+                calls["other"] += 1
+                return fn(*a, **k)
+            return w
+        dist.all_reduce, dist.all_gather, dist.broadcast = counted, other(real_ag), other(real_bc)
+        try:
+            for step in range(2):
+                ddp.arena.flat.fill_(float(rank + 1))
+                # the order bench.Workload.step uses: heads + decoder, encoder, backbone, finish
+                ddp.mark_ready(student.groups["heads"] + student.groups["decoder"])
+                ddp.mark_ready(student.groups["encoder"])
+                ddp.mark_ready(student.groups["backbone"])
+                ddp.finish()
+                assert torch.allclose(ddp.arena.flat, torch.full_like(ddp.arena.flat, (1 + world) / 2.0))
+        finally:
+            dist.all_reduce, dist.all_gather, dist.broadcast = real_ar, real_ag, real_bc
+        assert calls["all_reduce"] == 2 * len(ddp.arena.buckets) and len(ddp.arena.buckets) <= 4, calls
+        assert calls["elems"] == 2 * ddp.arena.numel and calls["other"] == 0, calls
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()[-1500:] or repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_bench_bucket_bookkeeping_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results

@@ -129,6 +129,39 @@ def test_mean_teacher_hook_semantics(golden_ema):
     assert abs(hook2.momentum - (1 - (1 - 0.999) / 0.1)) < 1e-12
 
 
+def test_ema_fast_path_notices_repointed_storage():
+    """the pointer table is reused while the Parameter OBJECTS are the same; a parameter re-pointed to new storage
+    (`p.data = ...`, module.to(), flattening) keeps its identity.  Sampled pairs are caught at once, any pair within 64 calls
+    -- and never is freed memory touched (the table keeps the old storage alive until it is rebuilt)."""
+    import semi_detr_amd.mean_teacher as mt
+    from semi_detr_amd import ema_update_
+    torch.manual_seed(0)
+    ts = [torch.nn.Parameter(torch.randn(100 + i, device="cuda")) for i in range(40)]
+    ss = [torch.nn.Parameter(torch.randn(100 + i, device="cuda")) for i in range(40)]
+    for _ in range(3):
+        ema_update_(ts, ss, 0.5)
+    for victim in (0, 5):                      # 0 is a sampled position, 5 is not
+        new = torch.randn_like(ss[victim].data)
+        ss[victim].data = new                   # re-pointed: same Parameter object, new storage
+        before = ts[victim].detach().clone()
+        calls = 0
+        while calls < mt._REVALIDATE_EVERY + 2:
+            ema_update_(ts, ss, 0.0)            # momentum 0: teacher <- student
+            calls += 1
+            if torch.equal(ts[victim].detach(), new):
+                break
+        assert torch.equal(ts[victim].detach(), new), "the re-pointed storage was never picked up"
+        assert calls == 1 if victim == 0 else calls <= mt._REVALIDATE_EVERY + 1, (victim, calls)
+        assert not torch.equal(before, new)
+    # a deleted model releases its table (weak references only)
+    del ts, ss
+    import gc
+    gc.collect()
+    a, b = [torch.randn(7, device="cuda")], [torch.randn(7, device="cuda")]
+    ema_update_(a, b, 0.0)
+    assert torch.equal(a[0], b[0]) and len(mt._table_cache) == 1
+
+
 def test_mean_teacher_vs_reference_hook_sequences(golden_ema):
     """semi_detr_amd.MeanTeacher with the real kernel against the sequences the reference's own hook produced
     (tests/golden/ema.npz seq.*: before_run clone, warm-up, interval 2, decay intervals, wrapped model)."""
