@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 #include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
 #include "msda_lw.h"     // LDS-window forward for encoder self-attention
 #include "msda_rw.h"     // region-window forward / gather for encoder self-attention
+#include "msda_own.h"    // owner-computes grad_value for arbitrary query sets
 #endif
 
 thread_local const char *g_last_kernels = "";
@@ -331,15 +332,23 @@ template <typename K>
 int allow_big_lds(K kern, size_t bytes, const char *what)
 {
     if (bytes <= 64 * 1024) return SEMIDETR_OK;
-    static thread_local int done_dev = -1;
-    static thread_local size_t done_bytes = 0;
+    // what was granted, per (kernel, device) of this thread: kernels of one signature share the pointer TYPE, so the
+    // bookkeeping is keyed on the pointer VALUE
+    struct Granted { const void *kern; int dev; size_t bytes; };
+    static thread_local Granted table[32];
+    static thread_local int used = 0;
+    const void *kp = reinterpret_cast<const void *>(kern);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess && (dev != done_dev || bytes > done_bytes)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e == hipSuccess) { done_dev = dev; done_bytes = bytes; }
-    }
+    if (e != hipSuccess) return semidetr::fail((int)e, "%s: hipGetDevice: %s", what, hipGetErrorString(e));
+    Granted *g = nullptr;
+    for (int i = 0; i < used; ++i)
+        if (table[i].kern == kp && table[i].dev == dev) g = &table[i];
+    if (g && g->bytes >= bytes) return SEMIDETR_OK;
+    e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return semidetr::fail((int)e, "%s: hipFuncSetAttribute(%zu bytes of LDS): %s", what, bytes, hipGetErrorString(e));
+    if (!g && used < 32) g = &table[used++];
+    if (g) *g = Granted{kp, dev, bytes};           // a full table only costs a repeated hipFuncSetAttribute
     return SEMIDETR_OK;
 }
 
@@ -426,26 +435,30 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
     if ((int64_t)N * Lq >= 512 && P <= 8) {
-        // level-aggregated scatter workgroups + gather workgroups side by side in ONE launch (msda_bwd_lvl_merged).
-        // Chunks of <= kLvlQ queries; small launches are cut finer so that at least ~128 scatter workgroups exist
-        // (micro-benchmark shape: 1 chunk 42.1 us, 2 chunks 36.1 us, 4 chunks 40.1 us)
-        int chunks = (Lq + kLvlQ - 1) / kLvlQ;
-        const int want = (128 + N * L * M - 1) / (N * L * M);
-        chunks = std::max(chunks, std::min(want, (Lq + 63) / 64));
+        // level-aggregated scatter workgroups + gather workgroups side by side in ONE launch (msda_bwd_lvl_merged_wide).
+        // bucketed levels: as many queries per workgroup as its LDS takes (fewest flushed rows); levels too large to bucket:
+        // <= 192 queries per workgroup (parallelism), and enough workgroups for small launches
+        const int qcap = P <= 4 ? kLvlQWide : kLvlQWide / 2;             // the entry list is chunk * P * 4 * 8 bytes
+        const int want = (128 + N * L * M - 1) / (N * L * M);            // small launches: >= ~128 scatter workgroups
+        const int fine = std::min(want, (Lq + 63) / 64);
+        const int chunks_b = std::max((Lq + qcap - 1) / qcap, fine), chunk_q_b = (Lq + chunks_b - 1) / chunks_b;
+        const int chunks = std::max(chunks_b, (Lq + 191) / 192);
         const int chunk_q = (Lq + chunks - 1) / chunks;
         const int gt = (Lq + 31) / 32;                                   // gather: 32 query rows per 256-thread block
         const int64_t gblocks = (int64_t)N * gt * M, sblocks = (int64_t)N * chunks * L * M;
         const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
-        const size_t slds = std::max((size_t)kLvlQ * kD * 4 + ((size_t)chunk_q * P * 4 + 8) * 8 + (size_t)2 * kLvlRows * 4,
-                                     2 * half_f4 * 16);
-        const int64_t grid = sblocks + (gblocks + 1) / 2;
+        constexpr int kParts = kLvlThreadsWide / 256;                    // gather blocks per workgroup
+        const size_t slds = std::max((size_t)kLvlQWide * kD * 4 + ((size_t)chunk_q_b * P * 4 + 8) * 8 + (size_t)2 * kLvlRows * 4,
+                                     kParts * half_f4 * 16);
+        const int64_t grid = sblocks + (gblocks + kParts - 1) / kParts;
         SEMIDETR_REQUIRE(grid < INT32_MAX && slds <= 159 * 1024, SEMIDETR_E_TOOLARGE, "msda_backward: merged launch too large");
 #define LAUNCH_MERGED(KLP_)                                                                                          \
         do {                                                                                                             \
-            auto kern = &msda_bwd_lvl_merged<IO, KLP_>;                                                                  \
+            auto kern = &msda_bwd_lvl_merged_wide<IO, KLP_>;                                                             \
             if (int rc = allow_big_lds(kern, slds, "msda_backward")) return rc;                                          \
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kLvlThreads), slds, st, grad_out, value, spatial_shapes, \
-                               level_start, io, S, M, L, Lq, P, chunks, chunk_q, (int)sblocks, gt, (int)gblocks, grad_value); \
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kLvlThreadsWide), slds, st, grad_out, value, spatial_shapes, \
+                               level_start, io, S, M, L, Lq, P, chunks, chunk_q, chunks_b, chunk_q_b, (int)sblocks, gt, (int)gblocks,      \
+                               grad_value);                                                                              \
         } while (0)
         if (L * P == 16) LAUNCH_MERGED(16);
         else LAUNCH_MERGED(0);

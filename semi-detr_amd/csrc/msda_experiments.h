@@ -243,6 +243,31 @@ int exp_launch_strips_backward(hipStream_t st, size_t fill, const float *grad_ou
         g_last_kernels = "fillBufferAligned+msda_bwd_lvl_merged";
         return semidetr::launch_status("msda_bwd_lvl_merged");
     }
+    if (g_bwd_variant == 910 && P <= 8 && (int64_t)Lq * P <= kOwnCap && (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0) {
+        // EXPERIMENT: owner-computes grad_value (stores only: no fill, no float atomics) + gather workgroups, ONE launch
+        // (msda_own.h).  Requires the levels to tile the value rows exactly (rows no level covers are not written): the
+        // tests that select it use canonical pyramids.
+        const int tb = own_tiles_bound(S, L);
+        const int gt = (Lq + 31) / 32;
+        const int64_t gblocks = (int64_t)N * gt * M, sblocks = (int64_t)N * tb * M;
+        const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;
+        const size_t slds = std::max(kOwnLdsBytes, 2 * half_f4 * 16);
+        const int64_t grid = sblocks + (gblocks + 1) / 2;
+        SEMIDETR_REQUIRE(grid < INT32_MAX && slds <= 159 * 1024, SEMIDETR_E_TOOLARGE, "msda_backward: merged launch too large");
+#define LAUNCH_OWN(KLP_, SPT_)                                                                                       \
+        do {                                                                                                             \
+            auto kern = &msda_bwd_own_merged<IO, KLP_, SPT_>;                                                            \
+            if (int rc = allow_big_lds(kern, slds, "msda_backward")) return rc;                                          \
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kOwnThreads), slds, st, grad_out, value, spatial_shapes, \
+                               level_start, io, S, M, L, Lq, P, tb, (int)sblocks, gt, (int)gblocks, grad_value);        \
+        } while (0)
+        const int spt = (Lq * P + kOwnThreads - 1) / kOwnThreads;
+        if (L * P == 16) { if (spt <= 3) LAUNCH_OWN(16, 3); else LAUNCH_OWN(16, 9); }
+        else             { if (spt <= 3) LAUNCH_OWN(0, 3);  else LAUNCH_OWN(0, 9); }
+#undef LAUNCH_OWN
+        g_last_kernels = "msda_bwd_own_merged";
+        return semidetr::launch_status("msda_bwd_own_merged");
+    }
     if (g_bwd_variant == 902 && P <= 8 && (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0) {
         // EXPERIMENT: cooperative zero fill inside the merged launch (msda_bwd_lvl_coop), no hipMemsetAsync.  The three
         // counters of a launch live in a library-owned device buffer (64 slots handed out round robin; the kernel leaves its

@@ -147,6 +147,28 @@ __device__ __forceinline__ float group8_sum(float x)
     return x;
 }
 
+// Three 8-lane sums at once, as nine fused v_add_f32_dpp (dst = dpp(src) + src).  Written by hand because the compiler packs the
+// adds of independent chains into v_pk_add_f32, which cannot take a DPP operand: every step then costs a v_mov_b32_dpp + an add
+// + wait states (the unrolled gather: 18 DPP-related instructions and ~6 s_nop per sample).  Interleaving the three chains puts
+// two independent instructions between a result and its next DPP read, which is exactly the hazard distance; the leading
+// s_nop 1 covers the producers of a / b / c.
+__device__ __forceinline__ void group8_sum3(float &a, float &b, float &c)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c));
+}
+
 // Softmax over the L*P logits of one (n, q, m) row (ms_deform_attn.py:101), evaluated cooperatively by the LP
 // consecutive threads that own the row's samples: one expf per sample, max / sum by xor-shuffles when LP is a
 // power of two <= 64 (the DINO case LP = 16 is one DPP row); any other LP falls back to a per-thread loop.
@@ -654,9 +676,7 @@ __device__ __forceinline__ void gather_body(
                 float pa = hh * hw * d1 + hh * lw * d2 + lh * hw * d3 + lh * lw * d4;
                 float px = a * (hh * (d2 - d1) + lh * (d4 - d3));
                 float py = a * (hw * (d3 - d1) + lw * (d4 - d2));
-                pa = group8_sum(pa);
-                px = group8_sum(px);
-                py = group8_sum(py);
+                group8_sum3(pa, px, py);
                 (void)l;
                 if ((k & 7) == j) {
                     // a real branch (the empty asm cannot be speculated): as selects, the scheduler hoists all 64 loads of
@@ -1226,17 +1246,21 @@ struct NoWait {
 
 // `before_atomics` runs (all threads) right before the first row atomic: the cooperative-fill launch waits there for the
 // zero fill of grad_value (msda_bwd_lvl_coop)
-template <typename IO, typename Wait = NoWait>
+// `chunks_b` / `chunk_q_b` (0 = as `chunks` / `chunk_q`): the chunking of the BUCKETED levels.  A bucketed level flushes fewer
+// rows the more queries share a workgroup, a level too large to bucket aggregates nothing and only wants parallelism; the
+// grid has `chunks` slots per (image, level, head), a bucketed level uses the first `chunks_b` of them.
+template <typename IO, typename Wait = NoWait, int NT = kLvlThreads, int LQ = kLvlQ>
 __device__ __forceinline__ void lvl_scatter_body(
     int b, float4 *smem, const float *__restrict__ gout, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int chunks, int chunk_q,
-    float *__restrict__ gvalue, const Wait before_atomics = Wait())
+    float *__restrict__ gvalue, const Wait before_atomics = Wait(), int chunks_b = 0, int chunk_q_b = 0)
 {
-    constexpr int NT = kLvlThreads, kStreams = NT / 16;
+    constexpr int kLvlQ = LQ;            // (shadows the file-scope default)
+    constexpr int kStreams = NT / 16;
     // layout: gtile [kLvlQ * 32 floats] | entries [emax float2] | cnt [kLvlRows] | start [kLvlRows]
     float *gtile = reinterpret_cast<float *>(smem);
     float2 *entries = reinterpret_cast<float2 *>(gtile + kLvlQ * kD);
-    const int emax = chunk_q * P * 4;
+    const int emax = max(chunk_q, chunk_q_b) * P * 4;
     int *cnt = reinterpret_cast<int *>(entries + emax + 8);
     int *start = cnt + kLvlRows;
     __shared__ int wsum[NT / 64], total_s;
@@ -1248,11 +1272,15 @@ __device__ __forceinline__ void lvl_scatter_body(
     const int m = b % M; b /= M;
     const int l = b % L; b /= L;
     const int ch = b % chunks, n = b / chunks;
-    const int q0 = ch * chunk_q, nq = min(chunk_q, Lq - q0);
-    if (nq <= 0) return;
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
     const int R = H * W;
     const bool bucket = R <= kLvlRows;
+    if (bucket && chunks_b > 0) {
+        if (ch >= chunks_b) return;
+        chunk_q = chunk_q_b;
+    }
+    const int q0 = ch * chunk_q, nq = min(chunk_q, Lq - q0);
+    if (nq <= 0) return;
 
     {   // grad_out rows of the chunk -> LDS, channels (c, c+16) interleaved; all loads of a thread are issued before its
         // stores (a load -> store loop would expose the global latency once per row)
@@ -1410,6 +1438,23 @@ __device__ __forceinline__ void lvl_scatter_body(
             }
         };
         int e = lo;
+        if (!bucket) {       // every entry is a row of its own: nothing to accumulate, eight independent atomics pairs per trip
+            for (; e < hi; e += 8) {
+                float2 en[8], gq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) en[u] = entries[min(e + u, hi - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gq[u] = gt2[(__float_as_int(en[u].y) & 1023) * 16 + l16];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (e + u >= hi) break;
+                    float *pr = gvs + (int64_t)((__float_as_int(en[u].y) >> 10) & 0xfffff) * rs;
+                    fp_atomic_add(pr, en[u].x * gq[u].x);
+                    fp_atomic_add(pr + 16, en[u].x * gq[u].y);
+                }
+            }
+            return;
+        }
         for (; e + 8 <= hi; e += 8) {
             float2 en[8], gq[8];
 #pragma unroll
@@ -1462,6 +1507,30 @@ __global__ __launch_bounds__(kLvlThreads) void msda_bwd_lvl_merged(
     const int vb = 2 * ((int)blockIdx.x - scatter_blocks) + half;
     const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;       // LDS of one gather block, in float4
     gather_body<IO, KLP, 0>(vb, (int)threadIdx.x & 255, smem + half * half_f4, vb < gather_blocks, gout, value, shapes,
+                            starts, io, S, M, L, Lq, P, gather_tiles);
+}
+
+// The same launch with 1024-thread workgroups (64 streams, four gather blocks per workgroup): the walk of the row-sorted
+// entries is a dependent chain per stream (fma -> test -> flush), so what bounds a workgroup is the LENGTH of a stream's
+// share, not the instruction count -- twice the streams on the same chunk halve it without flushing any more rows.
+constexpr int kLvlThreadsWide = 1024;
+constexpr int kLvlQWide = 384;           // queries per workgroup (48 KB of grad_out rows + 48 KB of entries at P = 4)
+template <typename IO, int KLP>
+__global__ __launch_bounds__(kLvlThreadsWide) void msda_bwd_lvl_merged_wide(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int chunks, int chunk_q,
+    int chunks_b, int chunk_q_b, int scatter_blocks, int gather_tiles, int gather_blocks, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    if ((int)blockIdx.x < scatter_blocks) {
+        lvl_scatter_body<IO, NoWait, kLvlThreadsWide, kLvlQWide>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, Lq, P,
+                                                                 chunks, chunk_q, gvalue, NoWait(), chunks_b, chunk_q_b);
+        return;
+    }
+    const int part = (int)threadIdx.x >> 8;
+    const int vb = (kLvlThreadsWide / 256) * ((int)blockIdx.x - scatter_blocks) + part;
+    const size_t half_f4 = (size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4;       // LDS of one gather block, in float4
+    gather_body<IO, KLP, 0>(vb, (int)threadIdx.x & 255, smem + part * half_f4, vb < gather_blocks, gout, value, shapes,
                             starts, io, S, M, L, Lq, P, gather_tiles);
 }
 

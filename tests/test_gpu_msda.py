@@ -84,7 +84,7 @@ def _random_case(seed, shapes, N, M, D, Lq, P, dtype, wide=True):
     return value, shapes, loc.astype(dtype), attn.astype(dtype), gout.astype(dtype)
 
 
-@pytest.mark.parametrize("variants", [(1, 8), (2, 32), (4, 8), (99, 99), (1, 808), (2, 832), (0, 0), (0, 900), (0, 901), (0, 902)])
+@pytest.mark.parametrize("variants", [(1, 8), (2, 32), (4, 8), (99, 99), (1, 808), (2, 832), (0, 0), (0, 900), (0, 901), (0, 902), (0, 910)])
 @pytest.mark.parametrize("Lq", [1, 7, 8, 9, 31, 32, 33, 300])
 def test_fast_path_variants_vs_oracle(variants, Lq):
     """Every forced kernel variant of the fp32 / D=32 path (forward split 1/2/4, backward 8/32 rows per
