@@ -591,8 +591,10 @@ static int check_fused(const void *value, const void *shapes, const void *starts
                      "Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
     SEMIDETR_REQUIRE(D == kD && L <= kMaxLevels && (int64_t)L * P <= 256 && slice_ok(S, M) && heads_ok(M), SEMIDETR_E_BADARG,
                      "msda_fused: only channels == 32 (got %d), <= %d levels, L*P <= 256, <= 32 heads, image slice < 4 GB", D, kMaxLevels);
-    SEMIDETR_REQUIRE((((uintptr_t)value | (uintptr_t)off) & 15) == 0, SEMIDETR_E_BADARG,
-                     "msda_fused: value / sampling_offsets must be 16-byte aligned");
+    SEMIDETR_REQUIRE((((uintptr_t)value | (uintptr_t)off | (uintptr_t)ref) & 15) == 0, SEMIDETR_E_BADARG,
+                     "msda_fused: value / sampling_offsets / reference_points must be 16-byte aligned");
+    SEMIDETR_REQUIRE((int64_t)N * Lq * L * ref_dim * 4 < (int64_t)0xFFFFFFF0u, SEMIDETR_E_TOOLARGE,
+                     "msda_fused: reference_points must be smaller than 4 GB");
     return SEMIDETR_OK;
 }
 
@@ -607,8 +609,9 @@ extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value,
                              attn_logits, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
         return rc;
     SEMIDETR_REQUIRE(out && ((uintptr_t)out & 15) == 0, SEMIDETR_E_BADARG, "msda_fused_forward: bad output pointer");
+    const unsigned ref_bytes = (unsigned)((int64_t)batch * num_query * num_levels * ref_dim * 4);
     const RawIO io = {reference_points, sampling_offsets, attn_logits, nullptr, nullptr, ref_dim, num_heads,
-                      num_levels, padding_mask, spatial_size};
+                      num_levels, padding_mask, spatial_size, ref_bytes};
     SEMIDETR_REQUIRE(!padding_mask || SEMIDETR_FWD_VARIANT == 0, SEMIDETR_E_BADARG,
                      "msda_fused_forward: the experimental kernel variants do not take a padding mask");
     return dispatch_fast_forward(semidetr::as_stream(stream), value, spatial_shapes, level_start, io, batch,
@@ -631,8 +634,9 @@ extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_
                      "msda_fused_backward: null pointer argument");
     SEMIDETR_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_value | (uintptr_t)grad_sampling_offsets) & 15) == 0,
                      SEMIDETR_E_BADARG, "msda_fused_backward: pointers must be 16-byte aligned");
+    const unsigned ref_bytes = (unsigned)((int64_t)batch * num_query * num_levels * ref_dim * 4);
     const RawIO io = {reference_points, sampling_offsets, attn_logits, grad_sampling_offsets, grad_attn_logits,
-                      ref_dim, num_heads, num_levels, padding_mask, spatial_size};
+                      ref_dim, num_heads, num_levels, padding_mask, spatial_size, ref_bytes};
     SEMIDETR_REQUIRE(!padding_mask || SEMIDETR_BWD_VARIANT == 0, SEMIDETR_E_BADARG,
                      "msda_fused_backward: the experimental kernel variants do not take a padding mask");
     return dispatch_fast_backward(semidetr::as_stream(stream), grad_out, value, spatial_shapes, level_start, io, batch,

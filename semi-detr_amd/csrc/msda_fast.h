@@ -12,6 +12,10 @@
 // layers) and do the softmax over L*P and the location arithmetic themselves, so the (N,Lq,M,L,P[,2])
 // intermediates (and their backward) never touch HBM.
 // ---------------------------------------------------------------------------------------------
+// 1 / x as ONE v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal -- on gfx950 the full IEEE division
+// sequence (v_div_scale / v_rcp / 4 fma / v_div_fmas / v_div_fixup), ten instructions where the fused prologue wants one.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 struct LocAttnIO {
     const float *loc, *attn;
     float *gloc, *gattn;
@@ -56,24 +60,32 @@ struct RawIO {
     // at bs 4) and the masking of grad_value never happen.
     const unsigned char *mask;
     int S;
+    unsigned ref_bytes;                          // size of `ref` (N * Lq * L * ref_dim floats): bound of its buffer resource
     static constexpr bool kSoftmax = true;       // load_w returns a raw logit; the kernel normalises the row
     __device__ __forceinline__ bool masked(int n, int pixel) const { return mask[(int64_t)n * S + pixel] != 0; }
     __device__ __forceinline__ bool has_mask() const { return mask != nullptr; }
     __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
-        const float *rp = ref + (nq * L + l) * ref_dim;
+        // BRANCH-FREE on purpose.  With `if (ref_dim == 2) ... else ...` around the loads every call became its own
+        // chain of basic blocks, and a kernel that calls load_xy for several samples "loads first" paid one global
+        // round trip PER SAMPLE instead of one in total (instrumented forward: record phase 9.9 k cycles against 4.7 k
+        // for the reference contract, the whole 10 % the fused prologue ran behind).  The reference point is one
+        // 16-byte buffer load for both layouts -- for ref_dim 2 it also picks up the next (query, level)'s point, unused;
+        // past the end of the tensor the buffer bound returns zeros -- and the two formulas differ by a uniform select.
         const float2 o = *reinterpret_cast<const float2 *>(off + (row * LP + k) * 2);
+        const float4 r = buf_ld4(image_rsrc(ref, ref_bytes), (unsigned)((nq * L + l) * ref_dim) * 4u);
+        finish_xy(o, r, P, H, W, x, y);
+    }
+    __device__ __forceinline__ void finish_xy(const float2 o, const float4 r, int P, int H, int W, float &x, float &y) const
+    {
         // x / W as x * rcp(W) (v_rcp_f32, 1 ulp): a true division is ~10 instructions per coordinate, and the location is
         // compared with the reference's to 1e-4, not bit for bit (the oracle-exact path is LocAttnIO)
-        if (ref_dim == 2) {          // ms_deform_attn.py:102-105
-            x = rp[0] + o.x * __frcp_rn((float)W);
-            y = rp[1] + o.y * __frcp_rn((float)H);
-        } else {                     // ms_deform_attn.py:106-108
-            const float ip = __frcp_rn((float)P);
-            x = rp[0] + o.x * ip * rp[2] * 0.5f;
-            y = rp[1] + o.y * ip * rp[3] * 0.5f;
-        }
+        const bool box = ref_dim == 4;               // ms_deform_attn.py:106-108 (boxes) vs :102-105 (points)
+        const float ip = 0.5f * fast_rcp((float)P);
+        const float sx = box ? ip * r.z : fast_rcp((float)W), sy = box ? ip * r.w : fast_rcp((float)H);
+        x = r.x + o.x * sx;
+        y = r.y + o.y * sy;
     }
     __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return logit[row * LP + k]; }
     // called by the LP consecutive threads that own the row's samples (see row_softmax)
@@ -96,11 +108,11 @@ struct RawIO {
         glogit[row * LP + k] = res.w * (res.x - dot);
         float2 g;
         if (ref_dim == 2) {
-            g = make_float2(res.y * __frcp_rn((float)W), res.z * __frcp_rn((float)H));
+            g = make_float2(res.y * fast_rcp((float)W), res.z * fast_rcp((float)H));
         } else {
-            const float *rp = ref + (nq * L + l) * ref_dim;
-            const float ip = __frcp_rn((float)P);
-            g = make_float2(res.y * 0.5f * rp[2] * ip, res.z * 0.5f * rp[3] * ip);
+            const float2 wh = *reinterpret_cast<const float2 *>(ref + (nq * L + l) * ref_dim + 2);
+            const float ip = 0.5f * fast_rcp((float)P);
+            g = make_float2(res.y * wh.x * ip, res.z * wh.y * ip);
         }
         *reinterpret_cast<float2 *>(goff + (row * LP + k) * 2) = g;
     }
@@ -206,14 +218,41 @@ __device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, 
         // As eight __shfl_xor per softmax the fused prologue ran 14 % behind the reference-contract kernels.
         const float mx = lp_group_max(raw, LP);
         const float e = __expf(raw - mx);
-        return e * __frcp_rn(lp_group_sum(e, LP));
+        return e * fast_rcp(lp_group_sum(e, LP));
     }
     float mx = raw;
     for (int j = 0; j < LP; ++j) mx = fmaxf(mx, io.load_w(row, LP, j));
     float sum = 0.f;
     for (int j = 0; j < LP; ++j) sum += __expf(io.load_w(row, LP, j) - mx);
     (void)k;
-    return __expf(raw - mx) * __frcp_rn(sum);
+    return __expf(raw - mx) * fast_rcp(sum);
+}
+
+// Two rows' softmax at once (the two samples a thread handles per trip of the record phase).  For L*P == 16 -- one DPP row per
+// query row, the DINO case -- both chains sit in ONE basic block with compile-time step counts, so the scheduler interleaves
+// them (a chain is 8 dependent DPP steps with two wait states each, an exp and a reciprocal).
+template <typename IO>
+__device__ __forceinline__ void row_softmax2(const IO &io, const int64_t (&rows)[2], int LP, const int (&kk)[2],
+                                             const float (&raw)[2], float (&a)[2])
+{
+    if (IO::kSoftmax && LP == 16) {
+        float m0 = raw[0], m1 = raw[1];
+        m0 = fmaxf(m0, dpp_mov<0xB1>(m0));  m1 = fmaxf(m1, dpp_mov<0xB1>(m1));
+        m0 = fmaxf(m0, dpp_mov<0x4E>(m0));  m1 = fmaxf(m1, dpp_mov<0x4E>(m1));
+        m0 = fmaxf(m0, dpp_mov<0x141>(m0)); m1 = fmaxf(m1, dpp_mov<0x141>(m1));
+        m0 = fmaxf(m0, dpp_mov<0x140>(m0)); m1 = fmaxf(m1, dpp_mov<0x140>(m1));
+        const float e0 = __expf(raw[0] - m0), e1 = __expf(raw[1] - m1);
+        float s0 = e0, s1 = e1;
+        s0 += dpp_mov<0xB1>(s0);  s1 += dpp_mov<0xB1>(s1);
+        s0 += dpp_mov<0x4E>(s0);  s1 += dpp_mov<0x4E>(s1);
+        s0 += dpp_mov<0x141>(s0); s1 += dpp_mov<0x141>(s1);
+        s0 += dpp_mov<0x140>(s0); s1 += dpp_mov<0x140>(s1);
+        a[0] = e0 * fast_rcp(s0);
+        a[1] = e1 * fast_rcp(s1);
+        return;
+    }
+    a[0] = row_softmax(io, rows[0], LP, kk[0], raw[0]);
+    a[1] = row_softmax(io, rows[1], LP, kk[1], raw[1]);
 }
 
 // The same softmax for an L*P that is not a power of two (five levels x four points = 20: the COCO-Full recipe), where the
@@ -244,7 +283,7 @@ __device__ __forceinline__ void softmax_rows_to_lds(const IO &io, int tid, int R
         sum += raw[i];
     }
     sum = group8_sum(sum);
-    const float inv = __frcp_rn(sum);
+    const float inv = fast_rcp(sum);
     if (row >= 0)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -343,11 +382,17 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     // PATCH: tiles_per_image is only a sizing hint for the grid -- a workgroup takes patches slot, slot + hint,
     // ... until the pyramid is exhausted, so any hint >= 1 is correct (the level table is device memory).
     for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
+#if SEMIDETR_EXPERIMENTS
+    const unsigned long long tm0 = __builtin_readcyclecounter();
+#endif
     if (PATCH) {
         pt = find_patch<PH ? PH : 1, PW ? PW : 1>(tile, shapes, starts, L);
         if (pt.Hq == 0) return;
         __syncthreads();      // previous patch done with the LDS records
     }
+#if SEMIDETR_EXPERIMENTS
+    const unsigned long long tm1 = __builtin_readcyclecounter();
+#endif
     auto query_of = [&](int r) { return PATCH ? patch_query<PW ? PW : 1>(pt, r) : (t.q0 + r < Lq ? t.q0 + r : -1); };
 
     // ---- phase 1: sample records -------------------------------------------------------------
@@ -359,29 +404,58 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
         });
         __syncthreads();
     }
-    for (int s = threadIdx.x; s < RPB * LP; s += 256) {
-        const int r = s / LP, k = s - r * LP;
-        const int q = query_of(r);
-        unsigned off[4] = {kOob, kOob, kOob, kOob};      // out of range -> the hardware returns zeros
-        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q >= 0) {
-            const int l = k / P;
+    // Two samples per thread and trip, every global load of both issued before any arithmetic and without a branch around
+    // them (an empty slot reads query 0 of the image): the loads' latencies overlap, and the two softmax reduction chains
+    // of the fused prologue (8 dependent DPP steps + exp + rcp each) interleave instead of running back to back -- the
+    // record phase is the serial section of a workgroup, everything it waits for is paid by the gather phase behind it.
+    for (int s0 = threadIdx.x; s0 < RPB * LP; s0 += 512) {
+        int rr[2], kk[2], qq[2];
+        float x[2], y[2], raw[2];
+        int64_t rows[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = s0 + 256 * u;
+            rr[u] = min(s / LP, RPB - 1);
+            kk[u] = s - (s / LP) * LP;
+            qq[u] = s < RPB * LP ? query_of(rr[u]) : -1;
+            const int l = kk[u] / P;
             const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
-            const int st = fixed_k ? stf : (int)starts[l];
-            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
-            float x, y, lw, lh;
-            io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
-            const float a = sm_lds ? rec_w[r * LPP + k].x : row_softmax(io, row, LP, k, io.load_w(row, LP, k));
-            if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                w = make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw));
-                mask_corners_oob(io, t.n, x, y, H, W, st, off);
-            }
+            const int64_t nq = (int64_t)t.n * Lq + max(qq[u], 0);
+            rows[u] = nq * M + t.m;
+            io.load_xy(rows[u], nq, LP, kk[u], l, P, H, W, x[u], y[u]);
+            raw[u] = sm_lds ? 0.f : io.load_w(rows[u], LP, kk[u]);
         }
-        rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
-        rec_w[r * LPP + k] = w;
+        float a[2];
+        if (sm_lds) {
+            a[0] = rec_w[rr[0] * LPP + kk[0]].x;
+            a[1] = rec_w[rr[1] * LPP + kk[1]].x;
+        } else {
+            row_softmax2(io, rows, LP, kk, raw, a);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (s0 + 256 * u >= RPB * LP) break;
+            unsigned off[4] = {kOob, kOob, kOob, kOob};      // out of range -> the hardware returns zeros
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qq[u] >= 0) {
+                const int l = kk[u] / P;
+                const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
+                const int st = fixed_k ? stf : (int)starts[l];
+                float lw, lh;
+                if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    w = make_float4(a[u] * (hh * hw), a[u] * (hh * lw), a[u] * (lh * hw), a[u] * (lh * lw));
+                    mask_corners_oob(io, t.n, x[u], y[u], H, W, st, off);
+                }
+            }
+            rec_off[rr[u] * LPP + kk[u]] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
+            rec_w[rr[u] * LPP + kk[u]] = w;
+        }
     }
     __syncthreads();
+#if SEMIDETR_EXPERIMENTS
+    const unsigned long long tm2 = __builtin_readcyclecounter();
+#endif
 
     // ---- phase 2: gather + weighted sum ------------------------------------------------------
     const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
@@ -417,6 +491,16 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
         const int64_t row = ((int64_t)t.n * Lq + q) * M + t.m;
         *reinterpret_cast<float4 *>(out + row * kD + 4 * j) = acc;
     }
+#if SEMIDETR_EXPERIMENTS
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 5) {      // sampled (1 workgroup in 64: the counters are global atomics) --
+        // wave 0's cycles per phase: 8 = patch search + previous patch's barrier, 9 = records, 10 = gather
+        const unsigned long long tm3 = __builtin_readcyclecounter();
+        SEMIDETR_DBG_ADD(8, tm1 - tm0);
+        SEMIDETR_DBG_ADD(9, tm2 - tm1);
+        SEMIDETR_DBG_ADD(10, tm3 - tm2);
+        SEMIDETR_DBG_ADD(11, 1);
+    }
+#endif
     if (!PATCH) return;
     }
 }
@@ -608,28 +692,52 @@ __device__ __forceinline__ void gather_body(
         });
         __syncthreads();
     }
-    for (int s = tid; s < RPB * LP; s += 256) {
-        const int r = s / LP, k = s - r * LP;
-        const int q = query_of(r);
-        unsigned off[4] = {kOob, kOob, kOob, kOob};
-        const int l = k / P;
-        float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
-        if (q >= 0) {
+    // two samples per thread and trip, all global loads first and unconditional (see msda_fwd_d32)
+    for (int s0 = tid; s0 < RPB * LP; s0 += 512) {
+        int rr[2], kk[2], qq[2];
+        float x[2], y[2], raw[2];
+        int64_t rows[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int s = s0 + 256 * u;
+            rr[u] = min(s / LP, RPB - 1);
+            kk[u] = s - (s / LP) * LP;
+            qq[u] = s < RPB * LP ? query_of(rr[u]) : -1;
+            const int l = kk[u] / P;
             const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
-            const int st = fixed_k ? stf : (int)starts[l];
-            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
-            float x, y, lw, lh;
-            io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
-            // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
-            pr.z = sm_lds ? rec_p[r * LPP + k].x : row_softmax(io, row, LP, k, io.load_w(row, LP, k));
-            if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
-                pr.x = lw;
-                pr.y = lh;
-                mask_corners_oob(io, t.n, x, y, H, W, st, off);
-            }
+            const int64_t nq = (int64_t)t.n * Lq + max(qq[u], 0);
+            rows[u] = nq * M + t.m;
+            io.load_xy(rows[u], nq, LP, kk[u], l, P, H, W, x[u], y[u]);
+            raw[u] = sm_lds ? 0.f : io.load_w(rows[u], LP, kk[u]);
         }
-        rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
-        rec_p[r * LPP + k] = pr;
+        float a[2];
+        if (sm_lds) {
+            a[0] = rec_p[rr[0] * LPP + kk[0]].x;
+            a[1] = rec_p[rr[1] * LPP + kk[1]].x;
+        } else {
+            row_softmax2(io, rows, LP, kk, raw, a);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (s0 + 256 * u >= RPB * LP) break;
+            unsigned off[4] = {kOob, kOob, kOob, kOob};
+            const int l = kk[u] / P;
+            float4 pr = make_float4(0.f, 0.f, 0.f, __int_as_float(l));
+            if (qq[u] >= 0) {
+                const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
+                const int st = fixed_k ? stf : (int)starts[l];
+                float lw, lh;
+                // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
+                pr.z = a[u];
+                if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
+                    pr.x = lw;
+                    pr.y = lh;
+                    mask_corners_oob(io, t.n, x[u], y[u], H, W, st, off);
+                }
+            }
+            rec_off[rr[u] * LPP + kk[u]] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
+            rec_p[rr[u] * LPP + kk[u]] = pr;
+        }
     }
     __syncthreads();
 

@@ -115,19 +115,35 @@ __device__ __forceinline__ void reg_scatter_body(
                 qs[sp] = i < nq ? qlist[i] : -1;
                 sm_max[sp] = 0.f;
                 sm_inv[sp] = 1.f;
-                if (IO::kSoftmax) {      // fused prologue: softmax statistics of the (query, head) row (quad reductions, P == 4)
-                    float mx = -__builtin_huge_valf();
-                    if (qs[sp] >= 0)
-                        for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow_of(qs[sp]), LP, l * P + p));
-                    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-                    float sum = 0.f;
-                    if (qs[sp] >= 0)
-                        for (int l = 0; l < L; ++l) sum += expf(io.load_w(srow_of(qs[sp]), LP, l * P + p) - mx);
-                    sum += __shfl_xor(sum, 1, 64);
-                    sum += __shfl_xor(sum, 2, 64);
+                if (IO::kSoftmax) {      // fused prologue: softmax statistics of the (query, head) row.  The thread's L logits
+                    // (its point on every level) are loaded ONCE, all loads in flight together; the four points of the row sit
+                    // in one quad (P == 4): two DPP steps per reduction.  __expf as in the forward / gather (row_softmax), so
+                    // the three kernels of an op agree on the weights to the last bit.
+                    constexpr int kLv = 8;       // levels held in registers (pyramids beyond that take the loops)
+                    const int64_t srow = srow_of(qs[sp] >= 0 ? qs[sp] : qlist[0]);
+                    float mx, sum = 0.f;
+                    if (L <= kLv) {
+                        float lg[kLv];
+#pragma unroll
+                        for (int l = 0; l < kLv; ++l) lg[l] = l < L ? io.load_w(srow, LP, l * P + p) : -__builtin_huge_valf();
+                        mx = lg[0];
+#pragma unroll
+                        for (int l = 1; l < kLv; ++l) mx = fmaxf(mx, lg[l]);
+                        mx = fmaxf(mx, dpp_mov<0xB1>(mx));
+                        mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+#pragma unroll
+                        for (int l = 0; l < kLv; ++l) sum += l < L ? __expf(lg[l] - mx) : 0.f;
+                    } else {
+                        mx = -__builtin_huge_valf();
+                        for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow, LP, l * P + p));
+                        mx = fmaxf(mx, dpp_mov<0xB1>(mx));
+                        mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+                        for (int l = 0; l < L; ++l) sum += __expf(io.load_w(srow, LP, l * P + p) - mx);
+                    }
+                    sum += dpp_mov<0xB1>(sum);
+                    sum += dpp_mov<0x4E>(sum);
                     sm_max[sp] = mx;
-                    sm_inv[sp] = 1.f / sum;
+                    sm_inv[sp] = fast_rcp(sum);
                 }
             }
             {   // stage grad_out of the queries, channels (c, c+16) interleaved; every load of a thread is issued before its
@@ -187,7 +203,7 @@ __device__ __forceinline__ void reg_scatter_body(
                         const float x = gx[sp], y = gy[sp];
                         if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
                             a = ga[sp];
-                            if (IO::kSoftmax) a = expf(a - sm_max[sp]) * sm_inv[sp];
+                            if (IO::kSoftmax) a = __expf(a - sm_max[sp]) * sm_inv[sp];
                             h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
                             w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
                             if (io.has_mask())      // padded pixels receive no gradient (fused prologue, see RawIO)
