@@ -87,6 +87,21 @@ int exp_launch_fast_forward(hipStream_t st, const float *value, const int64_t *s
             return semidetr::launch_status("msda_fwd_d32_lw");
         }
     }
+    if (g_fwd_variant >= 720 && g_fwd_variant <= 729 && pixels) {
+        // producer / consumer forward (msda_fwd_d32_ws): 4 consumer waves + 1 producer wave, the grid sized to the chip
+        // ((variant - 720) workgroups per CU, 0 -> 4).  Parity-green; measured 237.6 us (3 per CU) against 230.3 us for the
+        // default at bs 4 -- taking the record phase off the consumers' critical path buys nothing, the vector-memory path is
+        // limited by its misses in flight, not by how many waves feed it.
+        const int per_cu = g_fwd_variant == 720 ? 4 : g_fwd_variant - 720;
+        const int bound = (S + 31) / 32 * 5 / 4 + 4 * L;
+        const size_t wlds = (size_t)2 * 2 * 32 * (L * P + 1) * 16;
+        SEMIDETR_REQUIRE(wlds <= 64 * 1024, SEMIDETR_E_BADARG, "msda_forward: the producer / consumer kernel needs L * P <= 63");
+        const int hint = std::max(1, std::min(bound, (256 * per_cu + N * M - 1) / (N * M)));
+        hipLaunchKernelGGL((msda_fwd_d32_ws<IO>), dim3((unsigned)((int64_t)N * hint * M)), dim3(kWsThreads), wlds, st, value,
+                           spatial_shapes, level_start, io, S, M, L, Lq, P, hint, out);
+        g_last_kernels = "msda_fwd_d32_ws";
+        return semidetr::launch_status("msda_fwd_d32_ws");
+    }
     if (g_fwd_variant >= 700 && g_fwd_variant <= 709) {
         SEMIDETR_REQUIRE(pixels && P == kPT && (L == 4 || L == 5), SEMIDETR_E_BADARG,
                          "msda_forward: the region-window kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, 4 or 5 levels");

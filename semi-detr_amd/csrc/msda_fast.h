@@ -291,10 +291,12 @@ __device__ __forceinline__ void row_softmax2(const IO &io, const int64_t (&rows)
 // row's (not yet written) records; the kernel's record loop picks them up after ONE extra barrier.
 // rec: the float4 record array with LPP = LP + 1 entries per row; row_of(r) -> (n * Lq + q) * M + m or -1.
 template <typename IO, typename RowOf>
-__device__ __forceinline__ void softmax_rows_to_lds(const IO &io, int tid, int RPB, int LP, int LPP, float4 *rec, RowOf row_of)
+__device__ __forceinline__ void softmax_rows_to_lds(const IO &io, int tid, int RPB, int LP, int LPP, float4 *rec, RowOf row_of,
+                                                    int nthreads = 256)
 {
-    const int r = tid >> 3, j = tid & 7;
-    const int64_t row = r < RPB ? row_of(r) : -1;
+    const int j = tid & 7;
+    for (int r = tid >> 3; r < RPB; r += nthreads >> 3) {      // one trip for a 256-thread workgroup and 32 rows
+    const int64_t row = row_of(r);
     float raw[8], mx = -__builtin_huge_valf();            // LP <= 64 (checked by the launcher for this path)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -317,6 +319,7 @@ __device__ __forceinline__ void softmax_rows_to_lds(const IO &io, int tid, int R
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (j + 8 * i < LP) rec[r * LPP + j + 8 * i].x = raw[i] * inv;
+    }
 }
 
 // Workgroup -> (n, query tile, m).  Consecutive workgroups take consecutive heads, and the head of a given slot is
@@ -534,6 +537,137 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     }
 }
 
+#if SEMIDETR_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENT (forward variants 720-729): encoder self-attention forward, PRODUCER / CONSUMER form (queries are pixels, 4 x 8 patches as msda_fwd_d32<1,4,408>).
+//
+// Instrumented msda_fwd_d32 (wave-0 cycles per patch, bs 4): 950 waiting + 4600 in the record phase + 16 500 in the gather
+// phase -- a fifth of a workgroup's life goes into a phase that issues no corner load, and most of THAT is the latency of the
+// loads of the sampling locations / weights (HBM-cold, read once).  It cannot be prefetched by the waves that gather: vmcnt
+// is an in-order counter, a load issued before the gather loop is waited for by the loop's first s_waitcnt.  So the record
+// phase gets a wave of its own: a workgroup is 4 consumer waves + 1 producer wave and owns a SEQUENCE of patches (slot,
+// slot + hint, ...; the grid is sized to the chip, ~4 workgroups per CU); while the consumers gather patch i from one half
+// of the LDS records, the producer loads + computes the records of patch i + 1 into the other half; one barrier per patch.
+// The consumers' loop is the one of msda_fwd_d32.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWsThreads = 320;
+
+template <typename IO>
+__global__ __launch_bounds__(kWsThreads) void msda_fwd_d32_ws(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int Lq, int P, int hint, float *__restrict__ out)
+{
+    constexpr int RPB = 32, PH = 4, PW = 8;
+    extern __shared__ float4 smem[];
+    const int LP = L * P, LPP = LP + 1;
+    const int half_f4 = 2 * RPB * LPP;                 // one buffer: offsets + weights
+    const Tile t = tile_of_block(M, hint, RPB);
+    const int rs = M * kD;
+    const int tid = threadIdx.x;
+    const bool producer = tid >= 256;
+    const int lane = tid & 63;
+    // producer: sample s = lane + 64 u; for L*P dividing 64 its (level, point) is fixed
+    const bool fixed_k = (64 % LP) == 0;
+    const int lf = (lane % LP) / P;
+    const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
+    const bool sm_lds = IO::kSoftmax && !lp_shuffles(LP) && LP <= 64;
+
+    auto produce = [&](const Patch &pp, int buf) {
+        int4 *rec_off = reinterpret_cast<int4 *>(smem + buf * half_f4);
+        float4 *rec_w = smem + buf * half_f4 + RPB * LPP;
+        auto query_of = [&](int r) { return patch_query<PW>(pp, r); };
+        if (sm_lds) {      // L*P not a power of two: the row softmax by 8 threads per row, probabilities parked in rec_w.x
+            softmax_rows_to_lds(io, lane, RPB, LP, LPP, rec_w, [&](int r_) -> int64_t {
+                const int q_ = query_of(r_);
+                return q_ >= 0 ? ((int64_t)t.n * Lq + q_) * M + t.m : -1;
+            }, 64);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // one wave: its LDS writes are read back in order
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int s0 = lane; s0 < RPB * LP; s0 += 128) {
+            int rr[2], kk[2], qq[2];
+            float x[2], y[2], raw[2];
+            int64_t rows[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = s0 + 64 * u;
+                rr[u] = min(s / LP, RPB - 1);
+                kk[u] = s - (s / LP) * LP;
+                qq[u] = s < RPB * LP ? query_of(rr[u]) : -1;
+                const int l = kk[u] / P;
+                const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
+                const int64_t nq = (int64_t)t.n * Lq + max(qq[u], 0);
+                rows[u] = nq * M + t.m;
+                io.load_xy(rows[u], nq, LP, kk[u], l, P, H, W, x[u], y[u]);
+                raw[u] = sm_lds ? 0.f : io.load_w(rows[u], LP, kk[u]);
+            }
+            float a[2];
+            if (sm_lds) {
+                a[0] = rec_w[rr[0] * LPP + kk[0]].x;
+                a[1] = rec_w[rr[1] * LPP + kk[1]].x;
+            } else {
+                row_softmax2(io, rows, LP, kk, raw, a);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (s0 + 64 * u >= RPB * LP) break;
+                unsigned off[4] = {kOob, kOob, kOob, kOob};
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qq[u] >= 0) {
+                    const int l = kk[u] / P;
+                    const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
+                    const int st = fixed_k ? stf : (int)starts[l];
+                    float lw, lh;
+                    if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        w = make_float4(a[u] * (hh * hw), a[u] * (hh * lw), a[u] * (lh * hw), a[u] * (lh * lw));
+                        mask_corners_oob(io, t.n, x[u], y[u], H, W, st, off);
+                    }
+                }
+                rec_off[rr[u] * LPP + kk[u]] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
+                rec_w[rr[u] * LPP + kk[u]] = w;
+            }
+        }
+    };
+
+    int tile = t.q0 / RPB;
+    Patch cur = find_patch<PH, PW>(tile, shapes, starts, L);
+    if (cur.Hq == 0) return;
+    if (producer) produce(cur, 0);
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
+    for (int it = 0;; ++it) {
+        const Patch nxt = find_patch<PH, PW>(tile + hint, shapes, starts, L);
+        if (producer) {
+            if (nxt.Hq != 0) produce(nxt, (it + 1) & 1);
+        } else {
+            const int r = tid >> 3, j = tid & 7;
+            const int q = patch_query<PW>(cur, r);
+            const unsigned lane_b = (unsigned)(t.m * kD + 4 * j) * 4u;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int4 *ro = reinterpret_cast<const int4 *>(smem + (it & 1) * half_f4) + r * LPP;
+            const float4 *rw = smem + (it & 1) * half_f4 + RPB * LPP + r * LPP;
+#pragma unroll 4
+            for (int k = 0; k < LP; ++k) {
+                const int4 o = ro[k];
+                const float4 w = rw[k];
+                const float4 v1 = buf_ld4(vr, (unsigned)o.x + lane_b), v2 = buf_ld4(vr, (unsigned)o.y + lane_b);
+                const float4 v3 = buf_ld4(vr, (unsigned)o.z + lane_b), v4 = buf_ld4(vr, (unsigned)o.w + lane_b);
+                acc.x += w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
+                acc.y += w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
+                acc.z += w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
+                acc.w += w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
+            }
+            if (q >= 0) st_stream4(out + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j, acc);
+        }
+        if (nxt.Hq == 0) return;
+        __syncthreads();               // records of patch it + 1 complete, records of patch it free
+        cur = nxt;
+        tile += hint;
+    }
+}
+#endif      // SEMIDETR_EXPERIMENTS
+
 // Sum over the 32 lanes of each wavefront half (lane = channel).  After the five steps lanes 16..31 of
 // each half hold the half's total; the writer is lane 16 / 48.
 __device__ __forceinline__ float half32_sum(float x)
@@ -702,6 +836,9 @@ __device__ __forceinline__ void gather_body(
     const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
     // PATCH: tiles_per_image is a grid sizing hint; a workgroup takes patches slot, slot + hint, ... (see the forward)
     for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
+#if SEMIDETR_EXPERIMENTS
+    const unsigned long long tg0 = __builtin_readcyclecounter();
+#endif
     if (PATCH) {
         pt = find_patch<PH ? PH : 1, PW ? PW : 1>(tile, shapes, starts, L);
         if (PAIR) {
@@ -769,6 +906,9 @@ __device__ __forceinline__ void gather_body(
         }
     }
     __syncthreads();
+#if SEMIDETR_EXPERIMENTS
+    const unsigned long long tg1 = __builtin_readcyclecounter();
+#endif
 
     const int r = tid >> 3, j = tid & 7;
     const int q = query_of(r);
@@ -831,6 +971,9 @@ __device__ __forceinline__ void gather_body(
             mine[i].y *= lev_w[l];
             mine[i].z *= lev_h[l];
         }
+#if SEMIDETR_EXPERIMENTS
+        const unsigned long long tg2 = __builtin_readcyclecounter();
+#endif
         float dot = 0.f;                           // fused epilogue: sum_k a_k g_k over the row
         if (IO::kSoftmax) {
 #pragma unroll
@@ -846,6 +989,15 @@ __device__ __forceinline__ void gather_body(
                 if (k < KLP) io.store_with_dot(row, nq, LP, k, l, P_, (int)lev_h[l], (int)lev_w[l], mine[i], dot);
             }
         }
+#if SEMIDETR_EXPERIMENTS
+        if (tid == 0 && (bid & 63) == 5) {      // sampled wave-0 cycles: 12 = records (+ wait), 13 = gather loop, 14 = stores
+            const unsigned long long tg3 = __builtin_readcyclecounter();
+            SEMIDETR_DBG_ADD(12, tg1 - tg0);
+            SEMIDETR_DBG_ADD(13, tg2 - tg1);
+            SEMIDETR_DBG_ADD(14, tg3 - tg2);
+            SEMIDETR_DBG_ADD(15, 1);
+        }
+#endif
         if (!PATCH) return;
         continue;
     }

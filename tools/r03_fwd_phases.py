@@ -30,4 +30,19 @@ for io in ("locattn", "raw"):
     n = max(buf[11], 1)
     print(io, "us/launch %.1f" % (e0.elapsed_time(e1) * 100), "patches/launch", buf[11] // 10,
           "cycles per patch: wait %.0f records %.0f gather %.0f" % (buf[8] / n, buf[9] / n, buf[10] / n))
+    go = wl.t[("enc_gout", 4)]
+    fb = MSDA.ms_deform_attn_fused_backward if io == "raw" else MSDA.ms_deform_attn_backward
+    for _ in range(3):
+        fb(v, wl.shapes, wl.starts, *a, go, *extra)
+    torch.cuda.synchronize()
+    lib.semidetr_debug_counters(ctypes.cast(buf, ctypes.c_void_p), 1)
+    e0.record()
+    for _ in range(10):
+        fb(v, wl.shapes, wl.starts, *a, go, *extra)
+    e1.record()
+    torch.cuda.synchronize()
+    lib.semidetr_debug_counters(ctypes.cast(buf, ctypes.c_void_p), 1)
+    n = max(buf[15], 1)
+    print(io, "bwd us/launch %.1f" % (e0.elapsed_time(e1) * 100), "gather patches sampled/launch", buf[15] // 10,
+          "cycles per patch: records %.0f gather %.0f stores %.0f" % (buf[12] / n, buf[13] / n, buf[14] / n))
     del wl
