@@ -463,8 +463,8 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         if (L * P == 16) LAUNCH_MERGED(16);
         else LAUNCH_MERGED(0);
 #undef LAUNCH_MERGED
-        g_last_kernels = "fillBufferAligned+msda_bwd_lvl_merged";
-        return semidetr::launch_status("msda_bwd_lvl_merged");
+        g_last_kernels = "fillBufferAligned+msda_bwd_lvl_merged_wide";
+        return semidetr::launch_status("msda_bwd_lvl_merged_wide");
     }
     // small launches: one fused kernel after the fill; 32 query rows per workgroup, 8 when that would not fill 256 CUs
     const int rpb = (int64_t)N * M * ((Lq + 31) / 32) >= 1024 ? 32 : 8;

@@ -41,8 +41,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_product_code_object_holds_only_reachable_msda_kernels():
     """the product library's MSDA code object = the kernels its dispatcher can reach (28: forward patch /
-    strips x 3 splits, generic, gather x 3, region scatter, merged level scatter x 2, strips backward x 2 -- each for the
-    reference contract and the fused prologue, + fp64 generic), none of the rejected experiments."""
+    strips x 3 splits, generic, gather x 3, region scatter, 1024-thread merged level scatter x 2, strips backward x 2 -- each
+    for the reference contract and the fused prologue, + fp64 generic), none of the rejected experiments."""
     import subprocess
     csrc = os.path.join(ROOT, "semi-detr_amd", "csrc")
     syms = subprocess.run(["strings", "-a", os.path.join(csrc, "libsemidetr_hip.so")], capture_output=True, text=True).stdout
@@ -50,11 +50,12 @@ def test_product_code_object_holds_only_reachable_msda_kernels():
     names = set(re.findall(r"(_ZN12_GLOBAL__N_1\d+msda_[A-Za-z0-9_]+)\.kd", syms))
     assert 20 <= len(names) <= 30, sorted(names)
     for banned in ("msda_bwd_dest_d32", "msda_fwd_d32_lw", "msda_fwd_d32_res", "msda_bwd_enc_merged", "msda_bwd_encreg_merged",
-                   "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "msda_rw_d32", "stream_kernel"):
+                   "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "msda_rw_d32", "stream_kernel", "msda_bwd_own_merged",
+                   "msda_fwd_d32_ws", "msda_bwd_lvl_mergedI"):
         assert banned not in syms, banned
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(csrc, "libsemidetr_hip.so")],
                                           capture_output=True, text=True).stdout
-    assert kernels >= {"msda_fwd_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged", "msda_bwd_d32"}
+    assert kernels >= {"msda_fwd_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged_wide", "msda_bwd_d32"}
 
 
 def test_host_side_argument_errors_need_no_gpu():
