@@ -503,6 +503,20 @@ int exp_launch_fast_backward(hipStream_t st, const float *grad_out, const float 
             else if (L * P == 16 && g_bwd_variant == 6948)       // timing aid: nothing stored
                 hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, 4, 104>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
                                    st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound);
+            else if (L * P == 16 && g_bwd_variant == 920) {       // four lanes per query, 8 x 8 patches (msda_bwd_gather4_d32)
+                const int gbound4 = (S + 63) / 64 * 5 / 4 + 4 * L;
+                const size_t glds4 = (size_t)2 * 64 * (L * P + 1) * 16 + 2 * kMaxLevels * sizeof(float);
+                hipLaunchKernelGGL((msda_bwd_gather4_d32<IO, 16>), dim3((unsigned)((int64_t)N * gbound4 * M)), dim3(256), glds4, st,
+                                   grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound4,
+                                   fill_in_gather ? reinterpret_cast<float4 *>(grad_value) : nullptr, (int64_t)(fill / 16));
+            } else if (L * P == 16 && g_bwd_variant == 921)       // rolling window of 16 corner loads
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, 4, 16>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
+                                   st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound,
+                                   fill_in_gather ? reinterpret_cast<float4 *>(grad_value) : nullptr, (int64_t)(fill / 16));
+            else if (L * P == 16 && g_bwd_variant == 922)         // rolling window of 8 corner loads, 5 waves per SIMD
+                hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, 5, 8>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
+                                   st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound,
+                                   fill_in_gather ? reinterpret_cast<float4 *>(grad_value) : nullptr, (int64_t)(fill / 16));
             else if (fill_in_gather)
                 hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds,
                                    st, grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound,

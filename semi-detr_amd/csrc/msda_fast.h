@@ -850,6 +850,11 @@ __device__ __forceinline__ void gather_body(
     }
     const bool live = active && (!PATCH || pt.Hq != 0);
     auto query_of = [&](int rr_) { return !live ? -1 : (PATCH ? patch_query<PW ? PW : 1>(pt, rr_) : (t.q0 + rr_ < Lq ? t.q0 + rr_ : -1)); };
+    // this lane's piece of the query's grad_out row, requested BEFORE the record phase: it is read once (HBM-cold), and
+    // issued in front of the gather loop its latency sat, exposed, at the top of every patch's loop phase
+    const int q = query_of(tid >> 3);
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q >= 0) go = *reinterpret_cast<const float4 *>(gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * (tid & 7));
     const bool sm_lds = IO::kSoftmax && !lp_shuffles(LP) && LP <= 64;      // see softmax_rows_to_lds
     if (sm_lds) {
         softmax_rows_to_lds(io, tid, RPB, LP, LPP, rec_p, [&](int r_) -> int64_t {
@@ -911,11 +916,8 @@ __device__ __forceinline__ void gather_body(
 #endif
 
     const int r = tid >> 3, j = tid & 7;
-    const int q = query_of(r);
     const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
     const unsigned lane_b = (unsigned)(t.m * kD + 4 * j) * 4u;
-    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q >= 0) go = *reinterpret_cast<const float4 *>(gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j);
     const int4 *ro = rec_off + r * LPP;
     float4 *rp = rec_p + r * LPP;
     if constexpr (KLP > 0) {
@@ -926,6 +928,44 @@ __device__ __forceinline__ void gather_body(
 #pragma unroll
         for (int i = 0; i < NM; ++i) mine[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int P_ = KLP / L;                    // == P (checked by the launcher)
+        if constexpr (kB == 16 || kB == 8) {
+            constexpr int kAhead = kB / 4;             // samples in flight
+            // ROLLING window: 16 corner loads in flight all the time.  The batched form below issues 16 loads, waits, and
+            // computes four samples with nothing in flight behind them; here the four loads of sample s + 4 are issued as
+            // soon as sample s's corners have been reduced to their dot products -- same 64 registers of load data.
+            float4 buf[4 * kAhead];
+#pragma unroll
+            for (int s = 0; s < kAhead; ++s) {
+                const int4 o = ro[s];
+                buf[4 * s + 0] = buf_ld4(vr, (unsigned)o.x + lane_b);
+                buf[4 * s + 1] = buf_ld4(vr, (unsigned)o.y + lane_b);
+                buf[4 * s + 2] = buf_ld4(vr, (unsigned)o.z + lane_b);
+                buf[4 * s + 3] = buf_ld4(vr, (unsigned)o.w + lane_b);
+            }
+#pragma unroll
+            for (int k = 0; k < KLP; ++k) {
+                const float4 pr = rp[k];
+                const int4 on = ro[min(k + kAhead, KLP - 1)];
+                const unsigned onc[4] = {(unsigned)on.x, (unsigned)on.y, (unsigned)on.z, (unsigned)on.w};
+                float d[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 vv = buf[4 * (k % kAhead) + c];
+                    d[c] = go.x * vv.x + go.y * vv.y + go.z * vv.z + go.w * vv.w;
+                    if (k + kAhead < KLP) buf[4 * (k % kAhead) + c] = buf_ld4(vr, onc[c] + lane_b);
+                }
+                const float lw = pr.x, lh = pr.y, a = pr.z;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                float pa = hh * hw * d[0] + hh * lw * d[1] + lh * hw * d[2] + lh * lw * d[3];
+                float px = a * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
+                float py = a * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
+                group8_sum3(pa, px, py);
+                if ((k & 7) == j) {
+                    asm volatile("");      // a real branch, see below
+                    mine[k >> 3] = make_float4(pa, px, py, a);
+                }
+            }
+        } else {
 #pragma unroll
         for (int k0 = 0; k0 < KLP; k0 += kB) {
             int4 o[kB];
@@ -962,6 +1002,7 @@ __device__ __forceinline__ void gather_body(
                     mine[k >> 3] = make_float4(pa, px, py, a);
                 }
             }
+        }
         }
         // the W / H factors of grad_sampling_loc once per kept sample, after the loop: an LDS read inside the per-sample
         // branch put an `s_waitcnt lgkmcnt(0)` on every sample of the unrolled loop
@@ -1069,6 +1110,218 @@ __global__ __launch_bounds__(256, WPE) void msda_bwd_gather_d32(
     gather_body<IO, KLP, PATCH, false, KB>((int)blockIdx.x, (int)threadIdx.x, smem, true, gout, value, shapes, starts, io, S, M, L, Lq, P,
                                 tiles_per_image);
 }
+
+#if SEMIDETR_EXPERIMENTS
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENT (backward variant 920): the gather for encoder self-attention with FOUR lanes per query (8 channels each)
+// and 8 x 8 query patches.  Parity-green, 310 us against 305 us: HALF the vector instructions per query changed nothing.
+//
+// msda_bwd_gather_d32 (8 lanes per query, 4 channels each) is VALU-bound, not load-bound: ~1300 vector instructions per
+// wavefront and 32-query patch at 4 cycles each = 5.2 k cycles per SIMD and patch against 4.1 k cycles of corner loads per CU
+// (instrumented: gather loop 11.9 k of a patch's 17.9 k wave cycles, 67 % of the load path).  What does not shrink with the
+// channels per lane is everything AROUND the dot products -- the linear combinations that turn the four corner dots into
+// the three results, the cross-lane sums, the record reads, the address adds, the keep-my-sample select: ~40 of the ~60
+// vector instructions per sample.  With 8 channels per lane one pass of that overhead serves 16 queries of a wavefront
+// instead of 8 (3.6 vector instructions per query and sample instead of 7.9), the cross-lane sum is two quad_perm steps,
+// and the same 256 threads take an 8 x 8 patch, whose samples share more value rows (fewer L1 misses per read).
+// Loads in flight per lane as before (2 samples x 4 corners x 2 halves = 16 x 16 bytes).
+// ---------------------------------------------------------------------------------------------
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+
+// three sums over the 4 lanes of a quad at once: six fused v_add_f32_dpp, the chains interleaved (see group8_sum3)
+__device__ __forceinline__ void quad_sum3(float &a, float &b, float &c)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c));
+}
+
+template <typename IO, int KLP>
+__global__ __launch_bounds__(256, 4) void msda_bwd_gather4_d32(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image,
+    float4 *__restrict__ zero, int64_t zero_n4)
+{
+    static_assert(KLP % 4 == 0 && KLP <= 32, "results are spread over the 4 lanes of a quad");
+    constexpr int RPB = 64, PH = 8, PW = 8, LP = KLP, LPP = LP + 1, NM = KLP / 4;
+    extern __shared__ float4 smem[];
+    int4 *rec_off = reinterpret_cast<int4 *>(smem);
+    float4 *rec_p = smem + RPB * LPP;   // {lw, lh, a, -}
+    float *lev_w = reinterpret_cast<float *>(smem + 2 * RPB * LPP), *lev_h = lev_w + kMaxLevels;
+    const int tid = threadIdx.x;
+    if (zero) {      // side job: clear one slice of grad_value (the scatter launch that follows accumulates into it)
+        const int64_t per = (zero_n4 + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < zero_n4 ? lo + per : zero_n4;
+        for (int64_t i = lo + tid; i < hi; i += 256)
+            st_stream4(reinterpret_cast<float *>(zero + i), make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    const Tile t = tile_of_block(M, tiles_per_image, RPB);
+    const int rs = M * kD;
+    if (tid < L) {
+        lev_h[tid] = (float)shapes[2 * tid];
+        lev_w[tid] = (float)shapes[2 * tid + 1];
+    }
+    // 256 % LP == 0 for LP = 16; for LP = 20 a thread's (level, point) changes from sample to sample
+    const bool fixed_k = (256 % LP) == 0;
+    const int lf = (tid % LP) / P;
+    const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
+    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
+    for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
+        const Patch pt = find_patch<PH, PW>(tile, shapes, starts, L);
+        if (pt.Hq == 0) return;
+        __syncthreads();      // previous patch done with the LDS records (first trip: lev_w / lev_h written)
+        auto query_of = [&](int rr_) { return patch_query<PW>(pt, rr_); };
+        const bool sm_lds = IO::kSoftmax && !lp_shuffles(LP);      // see softmax_rows_to_lds
+        if (sm_lds) {
+            softmax_rows_to_lds(io, tid, RPB, LP, LPP, rec_p, [&](int r_) -> int64_t {
+                const int q_ = query_of(r_);
+                return q_ >= 0 ? ((int64_t)t.n * Lq + q_) * M + t.m : -1;
+            });
+            __syncthreads();
+        }
+        // ---- records: two samples per thread and trip, every global load first and unconditional (see msda_fwd_d32)
+        for (int s0 = tid; s0 < RPB * LP; s0 += 512) {
+            int rr[2], kk[2], qq[2];
+            float x[2], y[2], raw[2];
+            int64_t rows[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = s0 + 256 * u;
+                rr[u] = min(s / LP, RPB - 1);
+                kk[u] = s - (s / LP) * LP;
+                qq[u] = s < RPB * LP ? query_of(rr[u]) : -1;
+                const int l = kk[u] / P;
+                const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
+                const int64_t nq = (int64_t)t.n * Lq + max(qq[u], 0);
+                rows[u] = nq * M + t.m;
+                io.load_xy(rows[u], nq, LP, kk[u], l, P, H, W, x[u], y[u]);
+                raw[u] = sm_lds ? 0.f : io.load_w(rows[u], LP, kk[u]);
+            }
+            float a[2];
+            if (sm_lds) {
+                a[0] = rec_p[rr[0] * LPP + kk[0]].x;
+                a[1] = rec_p[rr[1] * LPP + kk[1]].x;
+            } else {
+                row_softmax2(io, rows, LP, kk, raw, a);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (s0 + 256 * u >= RPB * LP) break;
+                unsigned off[4] = {kOob, kOob, kOob, kOob};
+                float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qq[u] >= 0) {
+                    const int l = kk[u] / P;
+                    const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
+                    const int st = fixed_k ? stf : (int)starts[l];
+                    float lw, lh;
+                    pr.z = a[u];      // kept for skipped samples too: the softmax backward needs every probability
+                    if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
+                        pr.x = lw;
+                        pr.y = lh;
+                        mask_corners_oob(io, t.n, x[u], y[u], H, W, st, off);
+                    }
+                }
+                rec_off[rr[u] * LPP + kk[u]] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
+                rec_p[rr[u] * LPP + kk[u]] = pr;
+            }
+        }
+        __syncthreads();
+
+        // ---- gather: quad = query, lane j = channels 4j .. 4j+3 and 16+4j .. 16+4j+3
+        const int r = tid >> 2, j = tid & 3;
+        const int q = query_of(r);
+        const unsigned lane_b = (unsigned)(t.m * kD + 4 * j) * 4u;
+        v2f_t g0 = {0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+        if (q >= 0) {
+            const float *gp = gout + (((int64_t)t.n * Lq + q) * M + t.m) * kD + 4 * j;
+            const float4 lo4 = *reinterpret_cast<const float4 *>(gp), hi4 = *reinterpret_cast<const float4 *>(gp + 16);
+            g0 = v2f_t{lo4.x, lo4.y}; g1 = v2f_t{lo4.z, lo4.w}; g2 = v2f_t{hi4.x, hi4.y}; g3 = v2f_t{hi4.z, hi4.w};
+        }
+        const int4 *ro = rec_off + r * LPP;
+        const float4 *rp = rec_p + r * LPP;
+        float4 mine[NM];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) mine[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int kB = 2;                      // samples per batch: 2 x 4 corners x 2 halves = 16 loads in flight
+#pragma unroll
+        for (int k0 = 0; k0 < KLP; k0 += kB) {
+            int4 o[kB];
+            float4 pr[kB], v[kB][4][2];
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                o[u] = ro[k0 + u];
+                pr[u] = rp[k0 + u];
+            }
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const unsigned oc[4] = {(unsigned)o[u].x, (unsigned)o[u].y, (unsigned)o[u].z, (unsigned)o[u].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[u][c][0] = buf_ld4(vr, oc[c] + lane_b);
+                    v[u][c][1] = buf_ld4(vr, oc[c] + lane_b + 64u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const int k = k0 + u;
+                const float lw = pr[u].x, lh = pr[u].y, a = pr[u].z;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                // d_c = <grad_out, corner c> over this lane's 8 channels, as packed pairs
+                float d[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 va = v[u][c][0], vb = v[u][c][1];
+                    v2f_t tt = g0 * v2f_t{va.x, va.y};
+                    tt += g1 * v2f_t{va.z, va.w};
+                    tt += g2 * v2f_t{vb.x, vb.y};
+                    tt += g3 * v2f_t{vb.z, vb.w};
+                    d[c] = tt.x + tt.y;
+                }
+                const v2f_t d13 = {d[0], d[2]}, d24 = {d[1], d[3]};
+                const v2f_t tw = hw * d13 + lw * d24;              // (hw d1 + lw d2, hw d3 + lw d4)
+                const v2f_t ab = d24 - d13;                        // (d2 - d1, d4 - d3)
+                float pa = hh * tw.x + lh * tw.y;
+                float px = a * (hh * ab.x + lh * ab.y);
+                float py = a * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
+                quad_sum3(pa, px, py);
+                if ((k & 3) == j) {
+                    asm volatile("");      // a real branch: as selects the scheduler hoists every load of the unrolled loop
+                    mine[k >> 2] = make_float4(pa, px, py, a);
+                }
+            }
+        }
+        const int P_ = KLP / L;                    // == P (checked by the launcher)
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {             // the W / H factors of grad_sampling_loc, once per kept sample
+            const int l = min((j + 4 * i) / P_, L - 1);
+            mine[i].y *= lev_w[l];
+            mine[i].z *= lev_h[l];
+        }
+        float dot = 0.f;                           // fused epilogue: sum_k a_k g_k over the row
+        if (IO::kSoftmax) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) dot += mine[i].w * mine[i].x;
+            dot += dpp_mov<0xB1>(dot);
+            dot += dpp_mov<0x4E>(dot);
+        }
+        if (q >= 0) {
+            const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int k = j + 4 * i, l = min(k / P_, L - 1);
+                io.store_with_dot(row, nq, LP, k, l, P_, (int)lev_h[l], (int)lev_w[l], mine[i], dot);
+            }
+        }
+    }
+}
+#endif      // SEMIDETR_EXPERIMENTS
 
 // ---------------------------------------------------------------------------------------------
 // grad_value for encoder self-attention (num_query == spatial_size: the queries ARE the pixels of the
