@@ -4,11 +4,11 @@
 # rocprofv3 kernel statistics of the default bench command (-> profiles/r03_bench_kernel_stats.txt / _by_grid.txt).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R && mkdir -p gpurun_out
+timeout -k 5 1500 python tools/measure_traffic.py > gpurun_out/r03_traffic.log 2>&1; tail -3 gpurun_out/r03_traffic.log
+[ -f gpurun_out/r03_pmc_traffic.json ] && cp gpurun_out/r03_pmc_traffic.json profiles/r03_pmc_traffic.json
 timeout -k 5 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r03_final_tests.log
 cat gpurun_out/r03_final_tests.log
 timeout -k 5 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout -k 5 1500 python tools/measure_traffic.py > gpurun_out/r03_traffic.log 2>&1; tail -3 gpurun_out/r03_traffic.log
-[ -f gpurun_out/r03_pmc_traffic.json ] && cp gpurun_out/r03_pmc_traffic.json profiles/r03_pmc_traffic.json
 timeout -k 5 900 python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err
 tail -2 gpurun_out/r03_bench_default.err
 timeout 600 python bench.py --steps 10 --warmup 3 --io raw --no-cpu-baseline > gpurun_out/r03_bench_raw.json 2> gpurun_out/r03_bench_raw.err
