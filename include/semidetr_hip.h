@@ -95,7 +95,8 @@ int semidetr_msda_backward_f64(void *stream, const double *grad_out, const doubl
  *           together with MSDeformAttnFunction.apply (:121-123) and their autograd backward.
  * The kernels read the RAW outputs of the two Linear layers, so the (N,Lq,M,L,P,2) locations tensor, the
  * softmaxed weights and their gradients never exist in HBM.
- *   reference_points  (batch, num_query, num_levels, ref_dim)       ref_dim 2 or 4
+ *   reference_points  (batch, num_query, num_levels, ref_dim)       ref_dim 2 or 4; 16-byte aligned, < 4 GB (read with
+ *                     one bounded 16-byte buffer load per (query, level))
  *   sampling_offsets  (batch, num_query, num_heads, num_levels, num_point, 2)   raw Linear output
  *   attn_logits       (batch, num_query, num_heads, num_levels * num_point)     raw Linear output (pre-softmax)
  *   padding_mask      (batch, spatial_size) bytes, nonzero = padded pixel, or NULL: `value.masked_fill(mask[..., None], 0)`

@@ -232,6 +232,13 @@ Dims fused_dims(const at::Tensor &value, const at::Tensor &shapes, const at::Ten
     return d;
 }
 
+// The library reads reference points with 16-byte loads: a contiguous VIEW at an odd 8-byte offset (a batch slice of 2-d points
+// with an odd Lq * L) is copied into a fresh, aligned allocation -- small and rare.
+at::Tensor aligned16(const at::Tensor &t)
+{
+    return (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0 ? t : t.clone();
+}
+
 // input_padding_mask (N, S) bool / uint8, True = padding, or None: handed to the kernels as bytes
 const unsigned char *mask_ptr(const c10::optional<at::Tensor> &mask, const at::Tensor &value, const Dims &d)
 {
@@ -252,9 +259,10 @@ at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tenso
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
     at::Tensor out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, value.options());
     if (out.numel() == 0 || value.numel() == 0) return out.zero_();
+    const at::Tensor ref = aligned16(reference_points);
     const int rc = semidetr_msda_fused_forward_f32(
         stream_of(value), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(),
-        reference_points.data_ptr<float>(), (int)reference_points.size(-1), sampling_offsets.data_ptr<float>(),
+        ref.data_ptr<float>(), (int)reference_points.size(-1), sampling_offsets.data_ptr<float>(),
         attn_logits.data_ptr<float>(), mask_ptr(padding_mask, value, d), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
         self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), out.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_fused_forward");
@@ -275,9 +283,10 @@ std::vector<at::Tensor> ms_deform_attn_fused_backward(const at::Tensor &value, c
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
     at::Tensor gv = at::empty_like(value), go = at::empty_like(sampling_offsets), gl = at::empty_like(attn_logits);
     if (value.numel() == 0 || go.numel() == 0) return {gv.zero_(), go.zero_(), gl.zero_()};
+    const at::Tensor ref = aligned16(reference_points);
     const int rc = semidetr_msda_fused_backward_f32(
         stream_of(value), grad_output.data_ptr<float>(), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(),
-        level_start_index.data_ptr<int64_t>(), reference_points.data_ptr<float>(), (int)reference_points.size(-1),
+        level_start_index.data_ptr<int64_t>(), ref.data_ptr<float>(), (int)reference_points.size(-1),
         sampling_offsets.data_ptr<float>(), attn_logits.data_ptr<float>(), mask_ptr(padding_mask, value, d), d.N, d.S, d.M, d.D,
         d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), gv.data_ptr<float>(), go.data_ptr<float>(),
         gl.data_ptr<float>());

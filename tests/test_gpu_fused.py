@@ -161,6 +161,30 @@ def test_fused_errors():
                                           torch.zeros(1, 3, 2, 1, 1, 2).cuda(), torch.zeros(1, 3, 2, 1).cuda())
 
 
+def test_fused_reference_points_view_at_an_8_byte_offset():
+    """The kernels read a reference point with one 16-byte load; a contiguous batch slice of 2-d points with an odd Lq * L starts
+    8 bytes off -- the front end hands the library an aligned copy, and the last point's load runs into the buffer bound."""
+    import MultiScaleDeformableAttention as MSDA
+    torch.manual_seed(5)
+    N, Lq, M, L, P = 2, 3, 2, 1, 2
+    sh = torch.tensor([[3, 4]]).cuda()
+    ls = torch.tensor([0]).cuda()
+    v = torch.rand(N, 12, M, 32).cuda()
+    ref3 = torch.rand(N + 1, Lq, L, 2).cuda()
+    ref = ref3[1:]                                     # contiguous, data_ptr 24 bytes into the allocation
+    assert ref.is_contiguous() and ref.data_ptr() % 16 != 0
+    off = torch.randn(N, Lq, M, L, P, 2).cuda()
+    lg = torch.randn(N, Lq, M, L * P).cuda()
+    out = MSDA.ms_deform_attn_fused_forward(v, sh, ls, ref, off, lg)
+    want = MSDA.ms_deform_attn_fused_forward(v, sh, ls, ref.clone(), off, lg)
+    assert torch.equal(out, want)
+    go = torch.rand_like(out)
+    got = MSDA.ms_deform_attn_fused_backward(v, sh, ls, ref, off, lg, go)
+    exp = MSDA.ms_deform_attn_fused_backward(v, sh, ls, ref.clone(), off, lg, go)
+    for a, b in zip(got, exp):
+        assert torch.allclose(a, b, rtol=0, atol=1e-6)
+
+
 MASK_CASES = [
     ("dec_ref4", [(20, 27), (10, 14), (5, 7), (3, 4)], 2, 8, 70, 4, 4, False),      # strips backward
     ("dec_big", [(20, 27), (10, 14), (5, 7), (3, 4)], 2, 8, 300, 4, 4, False),      # N * Lq >= 512: merged level scatter
