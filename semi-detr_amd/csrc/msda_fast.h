@@ -878,7 +878,9 @@ __device__ __forceinline__ void gather_body(
             qq[u] = s < RPB * LP ? query_of(rr[u]) : -1;
             const int l = kk[u] / P;
             const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
-            const int64_t nq = (int64_t)t.n * Lq + max(qq[u], 0);
+            // an empty slot reads query 0 of the image; an INACTIVE half of a merged launch (block index past the last
+            // tile: its image index is one past the batch) reads query 0 of image 0
+            const int64_t nq = live ? (int64_t)t.n * Lq + max(qq[u], 0) : 0;
             rows[u] = nq * M + t.m;
             io.load_xy(rows[u], nq, LP, kk[u], l, P, H, W, x[u], y[u]);
             raw[u] = sm_lds ? 0.f : io.load_w(rows[u], LP, kk[u]);

@@ -20,6 +20,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--first", type=int, default=0, help="skip (but generate) the cases before this one")
+    ap.add_argument("--only", type=int, default=-1, help="run just this case of the sequence (the others only advance the generator)")
+    ap.add_argument("--verbose", action="store_true", help="print every case before it runs (to find a crashing one)")
     ap.add_argument("--variant", type=int, nargs=2, default=[0, 0], help="forced (fwd, bwd) kernel variants; cases a forced "
                     "variant does not apply to are skipped")
     a = ap.parse_args()
@@ -56,11 +59,17 @@ def main():
         attn /= attn.sum((-1, -2), keepdims=True)
         gout = rng.standard_normal((N, Lq, M * 32)).astype(np.float32)
         loc, attn = loc.astype(np.float32), attn.astype(np.float32)
+        if (a.only >= 0 and case != a.only) or case < a.first:
+            continue
+        if a.verbose:
+            print("case", case, shapes, "N", N, "M", M, "P", P, "Lq", Lq, "enc", enc, mode, file=sys.stderr, flush=True)
         tv, tl, ta, tg = (torch.from_numpy(x).cuda() for x in (value, loc, attn, gout))
         tsh = torch.from_numpy(shp).cuda()
         tls = torch.cat([tsh.new_zeros(1), (tsh[:, 0] * tsh[:, 1]).cumsum(0)[:-1]])
         try:
             out = MSDA.ms_deform_attn_forward(tv, tsh, tls, tl, ta, 64).cpu().numpy()
+            if a.verbose:
+                print("   forward done", file=sys.stderr, flush=True)
             gv, gl, ga = (t.cpu().numpy() for t in MSDA.ms_deform_attn_backward(tv, tsh, tls, tl, ta, tg, 64))
         except RuntimeError as e:
             if a.variant != [0, 0] and "need" in str(e):
