@@ -62,6 +62,7 @@ __device__ __forceinline__ void reg_scatter_body(
     const int nry = (Hb + RTH - 1) / RTH, nrx = (Wb + RTW - 1) / RTW;
 
     unsigned long long tmark = DBG ? __builtin_readcyclecounter() : 0ull;      // instrumented build: see msda_dest.h
+    (void)tmark;                                                               // (the product build's SEMIDETR_DBG_ADD is empty)
     auto lap = [&](int slot_) {
         if (DBG && tid == 0) {
             const unsigned long long now = __builtin_readcyclecounter();
