@@ -374,11 +374,15 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
         g_last_kernels = "msda_fwd_d32<1, 4, 408";
         return semidetr::launch_status("msda_fwd_d32<patch>");
     }
-    const int split = pick_split(0, N, Lq, M);
+    int split = pick_split(0, N, Lq, M);
+    // the records of a workgroup's rows have to fit the 64 KB every kernel may use without asking (L * P up to 256 is on this
+    // path: 32 rows x 257 records x 32 bytes would be 263 KB): fewer rows per workgroup for the very wide cases
+    while (split < 4 && (size_t)(32 / split) * (L * P + 1) * 32 > 64 * 1024) split *= 2;
     const int rpb = 32 / split;
     const int tiles = (Lq + rpb - 1) / rpb;
     SEMIDETR_REQUIRE((int64_t)N * tiles * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
     const size_t lds = (size_t)rpb * (L * P + 1) * 32;
+    if (int rc = allow_big_lds(&msda_fwd_d32<4, 4, 0, IO>, lds, "msda_forward")) return rc;      // only L * P > 255 at 8 rows
     if (split == 1) LAUNCH_FWD(1, 0, tiles, lds);
     else if (split == 2) LAUNCH_FWD(2, 0, tiles, lds);
     else LAUNCH_FWD(4, 0, tiles, lds);
@@ -434,7 +438,10 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     // ---- any query set
     hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
-    if ((int64_t)N * Lq >= 512 && P <= 8) {
+    // (four gather blocks of 2 * 32 * (L * P + 1) records share a merged workgroup's LDS: beyond L * P = 36 the launch takes
+    //  the strips kernel below)
+    const size_t merged_gather_lds = (size_t)(kLvlThreadsWide / 256) * ((size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4) * 16;
+    if ((int64_t)N * Lq >= 512 && P <= 8 && merged_gather_lds <= 159 * 1024) {
         // level-aggregated scatter workgroups + gather workgroups side by side in ONE launch (msda_bwd_lvl_merged_wide).
         // bucketed levels: as many queries per workgroup as its LDS takes (fewest flushed rows); levels too large to bucket:
         // <= 192 queries per workgroup (parallelism), and enough workgroups for small launches
@@ -467,11 +474,13 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         return semidetr::launch_status("msda_bwd_lvl_merged_wide");
     }
     // small launches: one fused kernel after the fill; 32 query rows per workgroup, 8 when that would not fill 256 CUs
-    const int rpb = (int64_t)N * M * ((Lq + 31) / 32) >= 1024 ? 32 : 8;
+    // (and 8 when 32 rows of records would not fit 64 KB of LDS: L * P > 62)
+    const int rpb = ((int64_t)N * M * ((Lq + 31) / 32) >= 1024 && (size_t)32 * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float) <= 64 * 1024) ? 32 : 8;
     const int tiles = (Lq + rpb - 1) / rpb;
     const int64_t grid = (int64_t)N * tiles * M;
     SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
     const size_t lds = (size_t)rpb * (L * P + 1) * 32 + 2 * kMaxLevels * sizeof(float);
+    if (int rc = allow_big_lds(&msda_bwd_d32<8, IO>, lds, "msda_backward")) return rc;      // only L * P > 254 at 8 rows
     if (rpb == 32)
         hipLaunchKernelGGL((msda_bwd_d32<32, IO>), dim3((unsigned)grid), dim3(256), lds, st, grad_out, value, spatial_shapes,
                            level_start, io, S, M, L, Lq, P, tiles, grad_value);
