@@ -359,9 +359,10 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
                         const int64_t *level_start, const IO &io, int N, int S, int M, int L, int Lq, int P,
                         int flags, float *out)
 {
-    const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0;
-    SEMIDETR_REQUIRE(!pixels || Lq == S, SEMIDETR_E_BADARG,
+    SEMIDETR_REQUIRE(!(flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) || Lq == S, SEMIDETR_E_BADARG,
                      "msda_forward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
+    // (a patch's 32 x (L * P + 1) records have to fit 64 KB: pyramids of more than 15 levels x 4 points take the strips)
+    const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0 && (size_t)32 * (L * P + 1) * 32 <= 63 * 1024;
 #define LAUNCH_FWD(SP, PT, TILES, LDS)                                                                          \
     hipLaunchKernelGGL((msda_fwd_d32<SP, 4, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        (LDS), st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
@@ -396,9 +397,9 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                          const int64_t *level_start, const IO &io, int N, int S, int M, int L, int Lq, int P,
                          int flags, float *grad_value)
 {
-    const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0;
-    SEMIDETR_REQUIRE(!pixels || Lq == S, SEMIDETR_E_BADARG,
+    SEMIDETR_REQUIRE(!(flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) || Lq == S, SEMIDETR_E_BADARG,
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
+    const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0 && (size_t)32 * (L * P + 1) * 32 <= 63 * 1024;
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     if (pixels && P == kPT && S < (1 << 23)) {
         // ---- encoder self-attention: patch gather (the two small gradients; it clears grad_value as a side job, the

@@ -368,7 +368,7 @@ def test_num_query_equal_spatial_size_without_pixel_queries():
 
 
 @pytest.mark.parametrize("L,P,Lq,N,Mh", [(8, 8, 300, 2, 2), (8, 8, 2100, 2, 8), (16, 8, 2100, 2, 8), (16, 16, 2100, 2, 8),
-                                          (9, 4, 700, 1, 8), (15, 4, 2100, 2, 8)])
+                                          (9, 4, 700, 1, 8), (15, 4, 2100, 2, 8), (16, 4, 0, 1, 4), (6, 4, 0, 2, 8)])
 def test_wide_level_point_products_vs_oracle(L, P, Lq, N, Mh):
     """num_levels * num_point up to 256 stays on the D = 32 path: the records of a workgroup's rows have to fit its LDS, so the
     dispatcher cuts the rows per workgroup (forward split, 8-row strips backward) and keeps the merged launch for L * P <= 36 --
@@ -379,6 +379,7 @@ def test_wide_level_point_products_vs_oracle(L, P, Lq, N, Mh):
     shapes = [(max(2, 12 - l), max(2, 14 - l)) for l in range(L)]
     shp = np.asarray(shapes, np.int64)
     S = int((shp[:, 0] * shp[:, 1]).sum())
+    Lq = Lq or S                                   # 0: encoder self-attention (queries are the pixels), many levels
     value = rng.random((N, S, Mh, 32)).astype(np.float32)
     loc = (rng.random((N, Lq, Mh, L, P, 2)) * 1.2 - 0.1).astype(np.float32)
     attn = rng.random((N, Lq, Mh, L, P)).astype(np.float32)
