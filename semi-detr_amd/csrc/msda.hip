@@ -449,8 +449,11 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         const int qcap = P <= 4 ? kLvlQWide : kLvlQWide / 2;             // the entry list is chunk * P * 4 * 8 bytes
         const int want = (128 + N * L * M - 1) / (N * L * M);            // small launches: >= ~128 scatter workgroups
         const int fine = std::min(want, (Lq + 63) / 64);
-        const int chunks_b = std::max((Lq + qcap - 1) / qcap, fine), chunk_q_b = (Lq + chunks_b - 1) / chunks_b;
-        const int chunks = std::max(chunks_b, (Lq + 191) / 192);
+        // ONE chunk for the bucketed levels whenever the queries fit (Lq <= 384, the two-stage Deformable-DETR / BASELINE shape):
+        // the workgroup then owns the level's rows of its (image, head) and STORES their sums instead of adding them atomically
+        // (lvl_scatter_body, "exclusive") -- micro-benchmark backward 36.3 -> 30.7 us, bs 4 / Lq 300 63 -> 53 us
+        const int chunks_b = Lq <= qcap ? 1 : std::max((Lq + qcap - 1) / qcap, fine), chunk_q_b = (Lq + chunks_b - 1) / chunks_b;
+        const int chunks = std::max(std::max(chunks_b, fine), (Lq + 191) / 192);
         const int chunk_q = (Lq + chunks - 1) / chunks;
         const int gt = (Lq + 31) / 32;                                   // gather: 32 query rows per 256-thread block
         const int64_t gblocks = (int64_t)N * gt * M, sblocks = (int64_t)N * chunks * L * M;
