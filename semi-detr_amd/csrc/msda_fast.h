@@ -1971,7 +1971,14 @@ __device__ __forceinline__ void lvl_scatter_body(
         // That needs every row summed by ONE stream: the shares are moved forward to the next row boundary.  (Several chunks
         // taken in turn by one workgroup with plain load-add-store was measured: decoder bs 4 / Lq 1100 239 us against 157,
         // bs 1 169 against 44 -- the chain gets three times as long and every flush waits for its load.)
-        const bool excl = bucket && chunks_b == 1;
+        bool excl = bucket && chunks_b == 1;
+        if (excl) {      // ... and nobody else's level may alias these rows (a level table whose levels overlap is legal input:
+            // the atomic form adds both levels' contributions correctly, stores would lose one)
+            for (int l2 = 0; l2 < L; ++l2) {
+                const int s2 = (int)starts[l2], r2 = (int)shapes[2 * l2] * (int)shapes[2 * l2 + 1];
+                if (l2 != l && s2 < st + R && st < s2 + r2) excl = false;
+            }
+        }
         if (excl) {
             auto aligned = [&](int x) {
                 if (x <= 0) return 0;

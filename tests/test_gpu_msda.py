@@ -395,3 +395,54 @@ def test_wide_level_point_products_vs_oracle(L, P, Lq, N, Mh):
     np.testing.assert_allclose(gv.cpu().numpy(), o_gv, rtol=0, atol=F32_GRAD_ATOL * max(1.0, float(np.abs(o_gv).max())))
     np.testing.assert_allclose(gl.cpu().numpy(), o_gl, rtol=1e-5, atol=F32_GRAD_ATOL * max(1.0, float(np.abs(o_gl).max())))
     np.testing.assert_allclose(ga.cpu().numpy(), o_ga, rtol=1e-5, atol=F32_GRAD_ATOL * max(1.0, float(np.abs(o_ga).max())))
+
+
+def _torch_msda(value, shapes, starts, loc, attn):
+    """Plain PyTorch fp32 statement of the op for an ARBITRARY level table (levels may leave gaps or overlap): bilinear
+    sampling by explicit corner gathers, zero padding outside a level (ms_deform_im2col_cuda.cuh:33-85, 237-299)."""
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = value.new_zeros(N, Lq, M, D)
+    n_i = torch.arange(N, device=value.device).view(N, 1, 1, 1)
+    m_i = torch.arange(M, device=value.device).view(1, 1, M, 1)
+    for l, (H, W) in enumerate(shapes):
+        x = loc[:, :, :, l, :, 0] * W - 0.5                 # (N, Lq, M, P)
+        y = loc[:, :, :, l, :, 1] * H - 0.5
+        x0, y0 = torch.floor(x), torch.floor(y)
+        lx, ly = x - x0, y - y0
+        for dy, dx, w in ((0, 0, (1 - ly) * (1 - lx)), (0, 1, (1 - ly) * lx), (1, 0, ly * (1 - lx)), (1, 1, ly * lx)):
+            xi, yi = (x0 + dx).long(), (y0 + dy).long()
+            ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+            row = starts[l] + yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)
+            v = value[n_i, row, m_i]                       # (N, Lq, M, P, D)
+            out = out + (v * (w * ok * attn[:, :, :, l, :])[..., None]).sum(3)
+    return out.reshape(N, Lq, M * D)
+
+
+@pytest.mark.parametrize("starts,S", [([0, 30, 500, 590], 640),       # levels 0 and 1 overlap (rows 30 .. 419), a gap before level 2
+                                      ([0, 420, 420, 600], 700),      # levels 1 and 2 share their first rows
+                                      ([0, 420, 540, 575], 590)])     # the canonical table (control)
+@pytest.mark.parametrize("Lq", [40, 300])
+def test_level_tables_with_overlapping_levels(starts, S, Lq):
+    """level_start_index is an input like any other: levels that alias the same value rows are legal for the reference (its
+    atomicAdd sums both levels' contributions).  The exclusive store form of the merged backward (one chunk of queries: Lq <= 384)
+    must notice the aliasing and fall back to atomics."""
+    import MultiScaleDeformableAttention as MSDA
+    shapes = [(20, 21), (10, 12), (5, 7), (3, 5)]
+    N, M, D, P, L = 2, 4, 32, 4, 4
+    g = torch.Generator(device="cuda").manual_seed(S + Lq)
+    value = torch.rand(N, S, M, D, generator=g, device="cuda")
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g, device="cuda") * 1.2 - 0.1
+    attn = torch.rand(N, Lq, M, L, P, generator=g, device="cuda") + 1e-3
+    attn = attn / attn.sum((-1, -2), keepdim=True)
+    gout = torch.randn(N, Lq, M * D, generator=g, device="cuda")
+    tsh = torch.tensor(shapes, device="cuda")
+    tls = torch.tensor(starts, device="cuda")
+    out = MSDA.ms_deform_attn_forward(value, tsh, tls, loc, attn, 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(value, tsh, tls, loc, attn, gout, 64)
+    v2, a2 = value.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+    ref = _torch_msda(v2, shapes, starts, loc, a2)
+    ref.backward(gout)
+    torch.testing.assert_close(out, ref.detach(), rtol=0, atol=5e-6)
+    torch.testing.assert_close(gv, v2.grad, rtol=0, atol=5e-5)
+    torch.testing.assert_close(ga, a2.grad, rtol=1e-5, atol=5e-5)
