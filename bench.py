@@ -48,9 +48,11 @@ RECIPES = {
     "coco10": dict(levels=LEVELS, n_sup=1, n_unsup=4),
     "full": dict(levels=LEVELS + [(7, 11)], n_sup=4, n_unsup=4),
 }
+ROT = 6                                                     # distinct input sets per MSDA group: one per layer of a pass
 GRAD_ELEMS = 60_000_000                                     # student DINO-R50 + projector
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_JSON = "r03_pmc_traffic.json"                           # written by tools/measure_traffic.py (rocprofv3 --pmc passes)
+PMC_JSON = "r04_pmc_traffic.json"                           # written by tools/measure_traffic.py (rocprofv3 --pmc passes)
+TA_JSON = "r04_fwd_enc_TA.json"                             # written by tools/r04_fwd_ta_evidence.sh
 
 
 def msda_alg_bytes(N, Lq, backward, S=S, L=L):
@@ -116,9 +118,10 @@ class StudentParams(torch.nn.Module):
 
 
 class Workload:
-    def __init__(self, dev, seed, recipe="coco10", io="locattn"):
+    def __init__(self, dev, seed, recipe="coco10", io="locattn", input_sets=ROT):
         import semi_detr_amd as sda
         self.sda, self.dev = sda, dev
+        self.rot = ROT = max(1, int(input_sets))      # noqa: N806 (shadows the module default on purpose)
         rc = RECIPES[recipe]
         self.recipe, self.io = recipe, io
         self.levels, self.n_sup, self.n_unsup = rc["levels"], rc["n_sup"], rc["n_unsup"]
@@ -145,29 +148,42 @@ class Workload:
             a = rand(n, lq, M, Lx, P) + 1e-5
             return (a / a.sum((-1, -2), keepdim=True)).contiguous()
 
+        # Every tensor of an MSDA group exists ROT times and the six layers of a pass take them in turn, as six layers with
+        # their own activations do: a bs-1 group's 80 MB working set replayed six times would sit in the 256 MB Infinity
+        # Cache.  self.t[key] is a list of ROT tensors.
         self.t = {}
+
+        def put(key, make):
+            self.t[key] = [make() for _ in range(ROT)]
+
         for n in sorted({1, 2, 4} if recipe == "coco10" else {self.n_sup, self.n_unsup}):
-            self.t[("value", n)] = rand(n, Sx, M, D) * 0.01
-            self.t[("enc_gout", n)] = rand(n, Sx, M * D)
+            put(("value", n), lambda: rand(n, Sx, M, D) * 0.01)
+            put(("enc_gout", n), lambda: rand(n, Sx, M * D))
             if io == "raw":      # the fused prologue's inputs: reference points, RAW offsets (pixels), RAW logits
-                self.t[("enc_ref", n)] = ref.view(1, Sx, 1, 2).expand(n, Sx, Lx, 2).contiguous()
-                self.t[("enc_off", n)] = (randn(n, Sx, M, Lx, P, 2) * 2.0).contiguous()
-                self.t[("enc_logit", n)] = (randn(n, Sx, M, Lx * P) * 2.0).contiguous()
+                put(("enc_ref", n), lambda: ref.view(1, Sx, 1, 2).expand(n, Sx, Lx, 2).contiguous())
+                put(("enc_off", n), lambda: (randn(n, Sx, M, Lx, P, 2) * 2.0).contiguous())
+                put(("enc_logit", n), lambda: (randn(n, Sx, M, Lx * P) * 2.0).contiguous())
             else:
-                self.t[("enc_loc", n)] = (ref.view(1, Sx, 1, 1, 1, 2) + randn(n, Sx, M, Lx, P, 2) * inv).contiguous()
-                self.t[("enc_attn", n)] = attn(n, Sx)
+                put(("enc_loc", n), lambda: (ref.view(1, Sx, 1, 1, 1, 2) + randn(n, Sx, M, Lx, P, 2) * inv).contiguous())
+                put(("enc_attn", n), lambda: attn(n, Sx))
             for lq in (NUM_QUERY, NUM_QUERY + DN_PAD):
                 # decoder: reference boxes anywhere, offsets scaled by the box size
-                c = rand(n, lq, 1, 1, 1, 2)
-                wh = rand(n, lq, 1, 1, 1, 2) * 0.3 + 0.02
-                if io == "raw":  # ref_dim 4: loc = c + off / P * wh * 0.5 (ms_deform_attn.py:106-108)
-                    self.t[("dec_ref", n, lq)] = torch.cat([c, wh], -1).view(n, lq, 1, 4).expand(n, lq, Lx, 4).contiguous()
-                    self.t[("dec_off", n, lq)] = (randn(n, lq, M, Lx, P, 2) * P).contiguous()
-                    self.t[("dec_logit", n, lq)] = (randn(n, lq, M, Lx * P) * 2.0).contiguous()
+                def dec_set(lq=lq):
+                    c = rand(n, lq, 1, 1, 1, 2)
+                    wh = rand(n, lq, 1, 1, 1, 2) * 0.3 + 0.02
+                    if io == "raw":  # ref_dim 4: loc = c + off / P * wh * 0.5 (ms_deform_attn.py:106-108)
+                        return (torch.cat([c, wh], -1).view(n, lq, 1, 4).expand(n, lq, Lx, 4).contiguous(),
+                                (randn(n, lq, M, Lx, P, 2) * P).contiguous(), (randn(n, lq, M, Lx * P) * 2.0).contiguous())
+                    return ((c + randn(n, lq, M, Lx, P, 2) * wh * 0.5).contiguous(), attn(n, lq))
+                sets = [dec_set() for _ in range(ROT)]
+                if io == "raw":
+                    self.t[("dec_ref", n, lq)] = [x[0] for x in sets]
+                    self.t[("dec_off", n, lq)] = [x[1] for x in sets]
+                    self.t[("dec_logit", n, lq)] = [x[2] for x in sets]
                 else:
-                    self.t[("dec_loc", n, lq)] = (c + randn(n, lq, M, Lx, P, 2) * wh * 0.5).contiguous()
-                    self.t[("dec_attn", n, lq)] = attn(n, lq)
-                self.t[("dec_gout", n, lq)] = rand(n, lq, M * D)
+                    self.t[("dec_loc", n, lq)] = [x[0] for x in sets]
+                    self.t[("dec_attn", n, lq)] = [x[1] for x in sets]
+                put(("dec_gout", n, lq), lambda: rand(n, lq, M * D))
         # matcher inputs: 7 layers x images, G ~ U{1..15}
         rng = np.random.default_rng(seed)
         self.asg = sda.HungarianAssigner(cls_cost=dict(type="FocalLossCost", weight=2.0),
@@ -221,21 +237,22 @@ class Workload:
         if self.record:
             self.events.append((name, launches, nbytes, e0, e1))
 
-    def _args(self, kind, n, lq):
+    def _args(self, kind, n, lq, r):
         if kind == "enc":
-            return ([self.t[("enc_ref", n)], self.t[("enc_off", n)], self.t[("enc_logit", n)]] if self.io == "raw"
-                    else [self.t[("enc_loc", n)], self.t[("enc_attn", n)]])
-        return ([self.t[("dec_ref", n, lq)], self.t[("dec_off", n, lq)], self.t[("dec_logit", n, lq)]] if self.io == "raw"
-                else [self.t[("dec_loc", n, lq)], self.t[("dec_attn", n, lq)]])
+            keys = [("enc_ref", n), ("enc_off", n), ("enc_logit", n)] if self.io == "raw" else [("enc_loc", n), ("enc_attn", n)]
+        else:
+            keys = ([("dec_ref", n, lq), ("dec_off", n, lq), ("dec_logit", n, lq)] if self.io == "raw"
+                    else [("dec_loc", n, lq), ("dec_attn", n, lq)])
+        return [self.t[k][r % self.rot] for k in keys]
 
     def _fwd(self, kind, n, lq, reps):
         import MultiScaleDeformableAttention as MSDA
-        v, a = self.t[("value", n)], self._args(kind, n, lq)
         fn = MSDA.ms_deform_attn_fused_forward if self.io == "raw" else MSDA.ms_deform_attn_forward
         im2col = () if self.io == "raw" else (64,)
+        calls = [(self.t[("value", n)][r % self.rot], self._args(kind, n, lq, r)) for r in range(reps)]      # layer r -> input set r
 
         def run():
-            for _ in range(reps):
+            for v, a in calls:
                 fn(v, self.shapes, self.starts, *a, *im2col)
         name = f"msda_fwd_{kind}_bs{n}_Lq{lq}"
         self._timed(name, reps, self.alg_bytes(n, lq, False), run)
@@ -244,13 +261,13 @@ class Workload:
 
     def _bwd(self, kind, n, lq, reps):
         import MultiScaleDeformableAttention as MSDA
-        v, a = self.t[("value", n)], self._args(kind, n, lq)
-        go = self.t[("enc_gout", n)] if kind == "enc" else self.t[("dec_gout", n, lq)]
+        gk = ("enc_gout", n) if kind == "enc" else ("dec_gout", n, lq)
         fn = MSDA.ms_deform_attn_fused_backward if self.io == "raw" else MSDA.ms_deform_attn_backward
         im2col = () if self.io == "raw" else (64,)
+        calls = [(self.t[("value", n)][r % self.rot], self._args(kind, n, lq, r), self.t[gk][r % self.rot]) for r in range(reps)]
 
         def run():
-            for _ in range(reps):
+            for v, a, go in calls:
                 fn(v, self.shapes, self.starts, *a, go, *im2col)
         name = f"msda_bwd_{kind}_bs{n}_Lq{lq}"
         self._timed(name, reps, self.alg_bytes(n, lq, True), run)
@@ -270,12 +287,21 @@ class Workload:
         self._timed("hungarian_batch", 1, 0,
                     lambda: self.asg.assign_batch(bp, cp, gts, labs, metas, check=False))
 
-    def step(self, ddp=None, record=False):
+    def step(self, ddp=None, record=False, reuse_encoder=False, backbone_cycles=0):
         """`ddp`: the dp.FlatDDP wrapper of the student's parameter list (None on one GPU).  The MSDA backward launches
         of this step are not autograd nodes, so the step tells the reducer which parameter groups have their final
         gradients -- through FlatDDP.mark_ready, the same bucket bookkeeping the autograd hooks drive in training
         (tests/test_dp_gloo.py runs those hooks under real autograd): decoder + heads after the decoder backward,
-        encoder after the encoder backward, backbone at the end of backward (FlatDDP.finish)."""
+        encoder after the encoder backward, backbone at the end of backward (FlatDDP.finish).
+
+        reuse_encoder: the call-site change of INTEGRATION.md 3.3 (NOT the reference's call structure, never the headline):
+        the student's no-grad forward (dino_detr_ssod.py:823) and its forward_dummy (:404) see the same features and the
+        same weights, and so do the teacher's simple_test_bboxes (:904) and forward_dummy (:364, :456); with dropout 0.0
+        (transformer.py:1053) the second encoder pass of each model recomputes the first one's memory -- 12 of the step's
+        24 unlabeled-batch encoder forwards.
+        backbone_cycles: a device-side sleep of that many clock ticks between the encoder backward and the end of
+        backward, standing in for the ResNet-50 backward this step omits (N > 1: its buckets then have something to
+        overlap with, which is the realistic case; 0 = the pessimistic one)."""
         self.record = record
         sda = self.sda
         ns, nu, Sx = self.n_sup, self.n_unsup, self.S
@@ -284,11 +310,15 @@ class Workload:
         self._fwd("enc", ns, Sx, 6); self._fwd("dec", ns, qd, 6)           # supervised student forward
         self._fwd("enc", nu, Sx, 6); self._fwd("dec", nu, q, 6)            # teacher simple_test
         self._timed("pseudo_label", 1, 0, self._pseudo)
-        self._fwd("enc", nu, Sx, 6); self._fwd("dec", nu, q, 6)            # student no-grad forward
+        if not reuse_encoder:
+            self._fwd("enc", nu, Sx, 6)                                    # student no-grad forward: encoder ...
+        self._fwd("dec", nu, q, 6)                                         # ... and decoder
         self._timed("pseudo_label", 0, 0, self._pseudo_finish)           # lists + weak->strong warp (compute_pseudo_label_loss)
         self._match(0)                                                   # inline matching, unsup_loss
-        self._fwd("enc", nu, Sx, 6); self._fwd("dec", nu, qd, 6)           # student forward_dummy
-        self._fwd("enc", nu, Sx, 6); self._fwd("dec", nu, qd, 6)           # teacher forward_dummy
+        self._fwd("enc", nu, Sx, 6); self._fwd("dec", nu, qd, 6)           # student forward_dummy (with grad)
+        if not reuse_encoder:
+            self._fwd("enc", nu, Sx, 6)                                    # teacher forward_dummy: encoder ...
+        self._fwd("dec", nu, qd, 6)                                        # ... and decoder
         self._match(1); self._match(2)                                   # sup + unsup loss()
         self._bwd("dec", nu, qd, 6); self._bwd("dec", ns, qd, 6)
         if ddp is not None:
@@ -296,9 +326,18 @@ class Workload:
         self._bwd("enc", nu, Sx, 6); self._bwd("enc", ns, Sx, 6)
         if ddp is not None:
             ddp.mark_ready(ddp.module.groups["encoder"])
-            # PESSIMISTIC by construction: in training the backbone's backward runs AFTER this point and its buckets overlap
-            # with it; here the backbone's 60 % of the arena becomes ready only now, so none of its reduction is hidden
-            ddp.mark_ready(ddp.module.groups["backbone"])
+        # backbone_cycles == 0 is PESSIMISTIC by construction: in training the backbone's backward runs AFTER the encoder's
+        # and its buckets overlap with it; without the stand-in the backbone's 60 % of the arena becomes ready only now,
+        # so none of its reduction is hidden.  With it: four slices of sleep, a quarter of the backbone's parameters
+        # (last layers first, the order backward finishes them) marked ready after each.
+        bb = list(reversed(ddp.module.groups["backbone"])) if ddp is not None else []
+        parts = 4 if backbone_cycles > 0 else 1
+        for i in range(parts):
+            if backbone_cycles > 0:
+                torch.cuda._sleep(int(backbone_cycles) // parts)         # the backbone's backward would run here
+            if ddp is not None:
+                ddp.mark_ready(bb[len(bb) * i // parts:len(bb) * (i + 1) // parts])
+        if ddp is not None:
             ddp.finish()
 
     def sup_step(self):
@@ -661,6 +700,11 @@ def cpu_baseline(wl=None):
     on a bounded sample: MSDA forward + backward on one encoder-shape and one decoder-shape image (backward as
     independent (head, level) tasks without atomics, and once serially), the 39 Hungarian problems of a step (oracle
     cost matrix + LSAP) and one EMA pass over the 47 M parameters.  Extrapolated linearly in images to one step."""
+    # threads pinned (the runtime reads these when liboracle.so's OpenMP runtime starts, i.e. before the first import of
+    # `oracle` in this process) and every leg the MEDIAN of >= 7 repetitions: 3 unpinned repetitions gave 0.0030 s and
+    # 0.0101 s for the same leg on two boxes (VERDICT r03)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import oracle
     cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
@@ -669,22 +713,27 @@ def cpu_baseline(wl=None):
     shapes = np.asarray(levels, np.int64)
     S, L = int((shapes[:, 0] * shapes[:, 1]).sum()), len(levels)
     value = (rng.random((1, S, M, D)) * 0.01).astype(np.float32)
-    t = {}
+    t, spread = {}, {}
+
+    def med(fn, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), [float(min(ts)), float(max(ts))]
+
     for kind, lq in (("enc", S), ("dec", NUM_QUERY + DN_PAD)):
         loc = rng.random((1, lq, M, L, P, 2)).astype(np.float32)
         a = rng.random((1, lq, M, L, P)).astype(np.float32)
         a /= a.sum((-1, -2), keepdims=True)
         go = rng.random((1, lq, M * D)).astype(np.float32)
-        oracle.msda_forward(value, shapes, loc, a)                      # warm the thread pool / page in
-        reps = 3 if kind == "enc" else 20
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            oracle.msda_forward(value, shapes, loc, a)
-        t[kind + "_f"] = (time.perf_counter() - t0) / reps
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        for _ in range(2):
+            oracle.msda_forward(value, shapes, loc, a)                  # warm the thread pool / page in
             oracle.msda_backward(value, shapes, loc, a, go, parallel=True)
-        t[kind + "_b"] = (time.perf_counter() - t0) / reps
+        reps = 9 if kind == "enc" else 21
+        t[kind + "_f"], spread[kind + "_f"] = med(lambda: oracle.msda_forward(value, shapes, loc, a), reps)
+        t[kind + "_b"], spread[kind + "_b"] = med(lambda: oracle.msda_backward(value, shapes, loc, a, go, parallel=True), reps)
         if kind == "enc":
             t0 = time.perf_counter()
             oracle.msda_backward(value, shapes, loc, a, go)
@@ -711,13 +760,56 @@ def cpu_baseline(wl=None):
     fwd_imgs, bwd_imgs = 6 * (n_sup + 4 * n_unsup), 6 * (n_sup + n_unsup)          # image-layers per step (enc and dec alike)
     step_s = fwd_imgs * (t["enc_f"] + t["dec_f"]) + bwd_imgs * (t["enc_b"] + t["dec_b"]) + t["match"] + t["ema"]
     return {"value": (n_sup + n_unsup) / step_s, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle (C + OpenMP, %d threads): msda fwd+bwd on 1 encoder-shape image (Lq=S, 3 reps) and 1 "
-                      "decoder-shape image (Lq=1100, 20 reps), extrapolated to the step's %d fwd / %d bwd image-layers; "
+            "sample": "oracle (C + OpenMP, %d threads, OMP_PROC_BIND=spread OMP_PLACES=cores): msda fwd+bwd on 1 encoder-shape image "
+                      "(Lq=S, median of 9) and 1 decoder-shape image (Lq=1100, median of 21), extrapolated to the step's %d fwd / "
+                      "%d bwd image-layers; "
                       "backward = independent (head, level) tasks, no atomics (serial backward stated beside it); "
                       "+ %d Hungarian problems (cost + LSAP, 1 thread) + one EMA pass over %d parameters (1 thread)"
                       % (cores, fwd_imgs, bwd_imgs, n_match, n_par),
             "enc_fwd_s": t["enc_f"], "enc_bwd_s": t["enc_b"], "enc_bwd_serial_1thread_s": t["enc_b_serial"],
-            "dec_fwd_s": t["dec_f"], "dec_bwd_s": t["dec_b"], "matcher_problems_s": t["match"], "ema_s": t["ema"]}
+            "dec_fwd_s": t["dec_f"], "dec_bwd_s": t["dec_b"], "matcher_problems_s": t["match"], "ema_s": t["ema"],
+            "min_max_s": spread}
+
+
+def comm_summary(ddp, stamps):
+    """exposed communication + per-bucket latency of the timed steps (FlatDDP.profile), see `collectives.note`."""
+    prof = []
+    for st in stamps:
+        if st:
+            ddp._last_stamps = st
+            prof.append(ddp.comm_profile())
+    if not prof:
+        return {"exposed_ms_per_step": None, "bucket_ready_to_done_ms": None}
+    nb = max(len(p["bucket_ready_to_done_ms"]) for p in prof)
+    per_bucket = [float(np.mean([p["bucket_ready_to_done_ms"][b] for p in prof if b < len(p["bucket_ready_to_done_ms"])]))
+                  for b in range(nb)]
+    return {"exposed_ms_per_step": float(np.mean([p["exposed_ms"] for p in prof])), "bucket_ready_to_done_ms": per_bucket}
+
+
+def run_flavour(dev, seed, recipe, io, steps=5, warmup=2, reuse_encoder=False, input_sets=ROT):
+    """A short run of another flavour of the step on the same device: ms per step, images/s and the roofline fraction of
+    its dominant MSDA group (algorithmic bytes / event-timed launch / 8 TB/s)."""
+    wl = Workload(dev, seed, recipe=recipe, io=io, input_sets=input_sets)
+    for _ in range(warmup):
+        wl.step(reuse_encoder=reuse_encoder)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step(record=True, reuse_encoder=reuse_encoder)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    stats = {k: v for k, v in wl.group_stats().items() if k.startswith("msda_")}
+    dom = max(stats, key=lambda k: stats[k]["ms"])
+    g = stats[dom]
+    us = g["ms"] * 1e3 / g["launches"]
+    enc_b = stats.get("msda_bwd_enc_bs%d_Lq%d" % (wl.n_unsup, wl.S))
+    res = {"ms_per_step": dt * 1e3, "images_per_s": wl.images_per_gpu / dt, "steps": steps, "dominant_kernel": dom,
+           "dominant_avg_launch_us": us, "dominant_frac_hbm_peak": g["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+           "enc_bwd_avg_launch_us": enc_b["ms"] * 1e3 / enc_b["launches"] if enc_b else None,
+           "kernels": wl.kernels.get(dom, [])}
+    del wl
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -734,6 +826,18 @@ def main():
                     help="locattn: the reference op contract (sampling locations + softmaxed weights); raw: the fused "
                          "MSDeformAttn prologue / epilogue the product module runs by default (reference points + raw offsets "
                          "+ raw logits)")
+    ap.add_argument("--reuse-encoder", action="store_true",
+                    help="NOT the reference's call structure (INTEGRATION.md 3.3): the student's and the teacher's second encoder "
+                         "pass over identical inputs reuse the first one's memory -- 12 fewer unlabeled-batch encoder forwards")
+    ap.add_argument("--backbone-ms", type=float, default=0.0,
+                    help="N > 1: a device-side sleep of this many milliseconds between the encoder backward and the end of "
+                         "backward stands in for the ResNet-50 backward the step omits, so the backbone's buckets overlap with "
+                         "something (realistic); 0 = pessimistic.  The sleep is subtracted from nothing: ms_per_step includes it")
+    ap.add_argument("--no-flavours", action="store_true", help="skip the short runs of the other step flavours")
+    ap.add_argument("--input-sets", type=int, default=ROT,
+                    help="distinct input sets per MSDA group, taken in turn by the six layers of a pass (default 6: every launch "
+                         "reads its inputs from HBM; 1 = the rounds 1-3 methodology, one set replayed -- the 91 MB value map of a "
+                         "bs-4 group then lives in the 256 MB Infinity Cache between launches)")
     ap.add_argument("--hold", type=float, default=0.0,
                     help="keep stepping (untimed) for this many seconds after the timed steps, so that an external GPU-busy "
                          "sampler sees the device working (the timed region of a default run is ~0.15 s)")
@@ -748,7 +852,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    wl = Workload(dev, seed=1234 + rank, recipe=args.recipe, io=args.io)
+    wl = Workload(dev, seed=1234 + rank, recipe=args.recipe, io=args.io, input_sets=args.input_sets)
     ipg = wl.images_per_gpu
     ddp = None
     if world > 1:
@@ -777,19 +881,36 @@ def main():
             return w
         dist.all_reduce, dist.all_gather, dist.broadcast = counted_all_reduce, counted_other(_ag), counted_other(_bc)
 
+    # --backbone-ms: torch.cuda._sleep takes clock ticks; calibrate ticks per millisecond on this device
+    backbone_cycles = 0
+    if args.backbone_ms > 0:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000000)
+        torch.cuda.synchronize()
+        e0.record()
+        torch.cuda._sleep(20000000)
+        e1.record()
+        torch.cuda.synchronize()
+        backbone_cycles = int(args.backbone_ms * 20000000 / e0.elapsed_time(e1))
+    kw = dict(reuse_encoder=args.reuse_encoder, backbone_cycles=backbone_cycles)
+    if ddp is not None:
+        ddp.profile = True
     for _ in range(args.warmup):
-        wl.step(ddp)
+        wl.step(ddp, **kw)
     barrier()
     coll.update(all_reduce=0, all_reduce_bytes=0, other=0)
+    comm_prof = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wl.step(ddp, record=True)
+        wl.step(ddp, record=True, **kw)
+        if ddp is not None:
+            comm_prof.append(ddp._last_stamps)       # resolved after the timed region (reading an event synchronises)
     barrier()
     elapsed = time.perf_counter() - t0
     coll_timed = dict(coll)
     t_hold = time.perf_counter()
     while args.hold > 0 and time.perf_counter() - t_hold < args.hold:      # untimed: lets a GPU-busy sampler see the device
-        wl.step(ddp)
+        wl.step(ddp, **kw)
         torch.cuda.synchronize()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -834,6 +955,13 @@ def main():
         fdur = fg["ms"] * 1e-3 / fg["launches"]
         clock_mhz = torch.cuda.get_device_properties(dev).clock_rate / 1e3 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2400.0
         l1_peak = 256 * 64 * 2400e6 / 1e9
+        # observed clock / TA busy fraction of this kernel: measured by tools/r04_fwd_ta_evidence.sh (rocprofv3 --pmc), read
+        # from the committed summary rather than carried as constants
+        try:
+            ta_ev = json.load(open(os.path.join(ROOT, "profiles", TA_JSON)))
+            obs_mhz, ta_frac = float(ta_ev["observed_clock_mhz"]), float(ta_ev["ta_busy_frac"])
+        except (OSError, ValueError, KeyError, TypeError):
+            ta_ev, obs_mhz, ta_frac = None, None, None
         out = {
             "metric": "images/sec/node DINO-R50 SSOD step (hot path: MSDA fwd/bwd + Hungarian + EMA/pseudo-label)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -845,19 +973,21 @@ def main():
                                     "filter + box warp; dense GEMMs/backbone not included")
                                    % ({"coco10": "COCO-10% (BASELINE.json configs[2]/[3])", "full": "COCO-Full (BASELINE.json configs[4])"}[args.recipe],
                                       wl.n_sup, wl.n_unsup, wl.S, wl.L, wl.S, wl.n_match, wl.n_params),
-                       "recipe": args.recipe, "io": args.io, "images_per_gpu": ipg,
+                       "recipe": args.recipe, "io": args.io, "images_per_gpu": ipg, "reuse_encoder": bool(args.reuse_encoder),
+                       "backbone_ms": args.backbone_ms, "input_sets_per_group": wl.rot,
                        "parallelism": "dp%d image-sharded, FlatDDP bucketed grad all-reduce of %d fp32 over RCCL" % (world, GRAD_ELEMS)
                        if world > 1 else "single GPU"},
             "roofline": roofline_of(dom_name),
             "roofline_l1": {"bound": "l1_return", "kernel": fwd_name, "kernel_symbols": wl.kernels.get(fwd_name, []),
                             "achieved": corner_bytes / fdur / 1e9, "peak": l1_peak, "unit": "GB/s",
                             "frac": corner_bytes / fdur / 1e9 / l1_peak,
-                            "frac_at_observed_clock": corner_bytes / fdur / 1e9 / (256 * 64 * 2190e6 / 1e9),
-                            "observed_clock_mhz": 2190.0, "ta_busy_frac_pmc": 0.80,
+                            "frac_at_observed_clock": (corner_bytes / fdur / 1e9 / (256 * 64 * obs_mhz * 1e6 / 1e9)) if obs_mhz else None,
+                            "observed_clock_mhz": obs_mhz, "ta_busy_frac_pmc": ta_frac,
+                            "pmc_source": ("profiles/" + TA_JSON) if ta_ev else None,
                             "note": "corner rows (4 x 128 B per sample) / launch time vs 256 CU x 64 B/clk x 2400 MHz; "
                                     "observed clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time and TA busy = TA_BUSY_avr / "
-                                    "active cycles from profiles/r02_fwd_enc_TA.txt (rocprofv3 --pmc, same kernel, probe "
-                                    "inputs).  This vector-memory INSTRUCTION path (16 cycles per 64-lane "
+                                    "active cycles, both read from profiles/" + TA_JSON + " (rocprofv3 --pmc, same kernel, probe "
+                                    "inputs; null when that file is missing).  This vector-memory INSTRUCTION path (16 cycles per 64-lane "
                                     "buffer_load_dwordx4: 450 k cycles per CU and launch = 84 % of the kernel at that clock) "
                                     "is what binds the forward and the gather; taking accesses off it through LDS cost more "
                                     "than it returned three times (DESIGN.md 2.1, profiles/r02_fwd_resident_level_pmc.txt, "
@@ -876,9 +1006,14 @@ def main():
                 "backend": dist.get_backend(), "world_size": world,
                 "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
                 "nccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))},
+                **comm_summary(ddp, comm_prof),
                 "note": "buckets of 64 MiB over a 240 MB gradient arena = 4 all-reduces per step, issued in arena order on every "
-                        "rank; the backbone's 60 % of the arena is marked ready only after the last MSDA backward launch, so "
-                        "its reduction is NOT overlapped here (pessimistic: in training the backbone's backward runs behind it)"}
+                        "rank.  exposed_ms_per_step = how long the compute stream waited for collectives after the last gradient "
+                        "was final (events on that stream); bucket_ready_to_done_ms = launch -> complete per bucket, averaged over "
+                        "the timed steps.  With --backbone-ms 0 the backbone's 60 % of the arena is marked ready only after the "
+                        "last MSDA backward launch, so its reduction is NOT overlapped (pessimistic: in training the backbone's "
+                        "backward runs behind it); --backbone-ms X puts a device-side sleep of X ms there, the backbone's "
+                        "parameters becoming ready in four slices (realistic)"}
         if world == 1 and not args.no_micro and args.recipe == "coco10" and args.io == "locattn":      # single-GPU extras
             # BASELINE.json config 2: supervised DINO-R50 bs 2 (hot path only), its own timed loop
             for _ in range(2):
@@ -892,9 +1027,42 @@ def main():
             out["supervised_dino_bs2"] = {"images_per_s": 2 / sup_s, "ms_per_step": sup_s * 1e3,
                                           "workload": "configs/dino_detr: 12 MSDA fwd + 12 MSDA bwd launches at bs 2 "
                                                       "(Lq=22223 / 1100) + 14 Hungarian problems; no EMA / pseudo labels"}
-            out["microbench"] = microbench(dev)
+            mb = microbench(dev)
+            out["microbench"] = mb
+            # the BASELINE micro-benchmark (N=2, Lq=300) where a reader of the top level finds it: COLD legs (8 rotated input
+            # sets, every launch reads its value map from HBM), against the 8 TB/s spec and the streaming rate measured in this
+            # run, on SURVEY 8(d)'s algorithmic bytes and on the counter bytes of profiles/<PMC_JSON> (FETCH_SIZE x2 + WRITE_SIZE)
+            cb = mb.get("counter_bytes") or {}
+            cf = cb.get("msda_fwd_micro_bs2_Lq300_cold", cb.get("msda_fwd_micro_bs2_Lq300"))
+            cbw = cb.get("msda_bwd_micro_bs2_Lq300_cold", cb.get("msda_bwd_micro_bs2_Lq300"))
+            for leg, nbytes_c in (("fwd", cf), ("bwd", cbw), ("fwd_bwd", (cf + cbw) if cf and cbw else None)):
+                c = mb["cold"][leg]
+                out["microbench_cold_%s_us" % leg] = c["us"]
+                out["microbench_cold_%s_frac_spec" % leg] = c["frac_hbm_spec"]
+                out["microbench_cold_%s_frac_measured" % leg] = c["frac_hbm_measured"]
+                out["microbench_cold_%s_frac_spec_counter_bytes" % leg] = (nbytes_c / (c["us"] * 1e-6) / (HBM_PEAK_GBS * 1e9)
+                                                                           if nbytes_c else None)
+                out["microbench_cold_%s_frac_measured_counter_bytes" % leg] = (
+                    nbytes_c / (c["us"] * 1e-6) / (mb["hbm_stream_measured_gbs"] * 1e9) if nbytes_c else None)
             out["module_fused_prologue"] = module_bench(dev)
             out["warmup_stage"] = warmup_stage_bench(dev)
+        if world == 1 and not args.no_flavours and args.recipe == "coco10" and args.io == "locattn" and not args.reuse_encoder:
+            # the other flavours of the step, 5 steps each (the driver's record then answers "COCO-Full images/s" and
+            # "fused-path images/s" by itself); the headline above stays the reference-contract COCO-10 % step
+            del wl.t
+            torch.cuda.empty_cache()
+            out["flavours"] = {"raw": run_flavour(dev, 1234, "coco10", "raw"),
+                               "full": run_flavour(dev, 1234, "full", "locattn"),
+                               "full_raw": run_flavour(dev, 1234, "full", "raw"),
+                               "reuse_encoder": run_flavour(dev, 1234, "coco10", "locattn", reuse_encoder=True),
+                               "replayed_inputs": run_flavour(dev, 1234, "coco10", "locattn", input_sets=1)}
+            out["flavours"]["note"] = ("raw = the fused MSDeformAttn prologue kernels the product module runs by default; full = "
+                                       "COCO-Full recipe (BASELINE.json configs[4]: 4 + 4 images, five levels); reuse_encoder = the "
+                                       "call-site change of INTEGRATION.md 3.3 (12 fewer encoder forwards), NOT the reference's call "
+                                       "structure; replayed_inputs = the headline step with ONE input set per group replayed by all six "
+                                       "layers (--input-sets 1), the methodology of rounds 1-3: the value map of a group then stays in the "
+                                       "Infinity Cache between launches, which a training step -- six layers, six activations -- does "
+                                       "not offer; comparable with BENCH_r01..r03, not with the headline of this line")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out))

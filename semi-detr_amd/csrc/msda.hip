@@ -246,6 +246,9 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 }
 
 #include "msda_fast.h"   // IO policies + the D == 32 fp32 kernels
+#if SEMIDETR_EXPERIMENTS
+#include "msda_fast_experiments.h"   // windowed scatter, resident-level forward, 512-thread merged / cooperative-fill backward
+#endif
 #include "msda_region.h" // region-owned windowed scatter for encoder self-attention
 #if SEMIDETR_EXPERIMENTS    // negative results kept as evidence: only in libsemidetr_hip_exp.so
 #include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
@@ -442,7 +445,9 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     // (four gather blocks of 2 * 32 * (L * P + 1) records share a merged workgroup's LDS: beyond L * P = 36 the launch takes
     //  the strips kernel below)
     const size_t merged_gather_lds = (size_t)(kLvlThreadsWide / 256) * ((size_t)2 * 32 * (L * P + 1) + 2 * kMaxLevels / 4 + 4) * 16;
-    if ((int64_t)N * Lq >= 512 && P <= 8 && merged_gather_lds <= 159 * 1024) {
+    // (S < 2^20: lvl_scatter_body packs a level-local row index into 20 bits of its entry word -- ADVICE r03; larger maps take
+    //  the strips kernel below)
+    if ((int64_t)N * Lq >= 512 && P <= 8 && merged_gather_lds <= 159 * 1024 && S < (1 << 20)) {
         // level-aggregated scatter workgroups + gather workgroups side by side in ONE launch (msda_bwd_lvl_merged_wide).
         // bucketed levels: as many queries per workgroup as its LDS takes (fewest flushed rows); levels too large to bucket:
         // <= 192 queries per workgroup (parallelism), and enough workgroups for small launches

@@ -417,13 +417,44 @@ int exp_launch_fast_backward(hipStream_t st, const float *grad_out, const float 
         // forces the memset.  (The same idea for arbitrary query sets -- gather + fill, then the level scatter as a second
         // launch, variant 901 -- loses against the merged launch: micro-benchmark 36.2 -> 41-44 us, decoder bs 4 161 -> 169.)
         const bool rw_gather = g_bwd_variant >= 7000 && g_bwd_variant <= 7009 && P == kPT && (L == 4 || L == 5);
-        const bool gather_kernel_runs = !(g_bwd_variant == 697 || g_bwd_variant == 68);
+        const bool gather_kernel_runs = !(g_bwd_variant == 697 || g_bwd_variant == 68 || (g_bwd_variant >= 6900 && g_bwd_variant <= 6919));
         const bool fill_in_gather = (L * P == 16 || rw_gather) && gather_kernel_runs && g_bwd_variant != 6991 && g_bwd_variant != 66 &&
                                     g_bwd_variant != 67 && g_bwd_variant != 6962 && g_bwd_variant != 6952 && g_bwd_variant != 6948 &&
                                     (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0;
         if (!fill_in_gather) {
             hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
             if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
+        }
+        if (g_bwd_variant >= 6900 && g_bwd_variant <= 6919 && P == kPT && S < (1 << 23)) {
+            // round 4: the whole encoder backward in ONE kernel after the fill (msda_bwd_enc_fused_d32); 6901 = instrumented
+            const int rbound = (S + 127) / 128 * 5 / 4 + 4 * L;
+            const int64_t rgrid = (int64_t)N * rbound * M;
+            SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+            const size_t rlds = reg_lds_bytes<512, 208, 24, 32, 1>();
+#define LAUNCH_FUSED(DBG_, AID_) LAUNCH_FUSEDZ(DBG_, AID_, 1)
+#define LAUNCH_FUSEDZ(DBG_, AID_, FZ_)                                                                                     \
+            do {                                                                                                             \
+                auto kern = &msda_bwd_enc_fused_d32<IO, 512, 208, 8, 16, 24, 32, DBG_, 4, 8, AID_, FZ_>;                     \
+                if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;                                          \
+                hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, value, spatial_shapes,        \
+                                   level_start, io, S, M, L, rbound, grad_value);                                            \
+            } while (0)
+            if (g_bwd_variant == 6901) LAUNCH_FUSED(1, 0);
+            else if (g_bwd_variant == 6902) LAUNCH_FUSED(0, 1);       // timing aids (results wrong), see reg_scatter_body
+            else if (g_bwd_variant == 6903) LAUNCH_FUSED(0, 2);
+            else if (g_bwd_variant == 6904) LAUNCH_FUSED(0, 4);
+            else if (g_bwd_variant == 6905) LAUNCH_FUSED(0, 8);
+            else if (g_bwd_variant == 6906) LAUNCH_FUSED(0, 16);
+            else if (g_bwd_variant == 6907) LAUNCH_FUSED(0, 7);
+            else if (g_bwd_variant == 6908) LAUNCH_FUSED(0, 24);
+            else if (g_bwd_variant == 6909) LAUNCH_FUSEDZ(0, 0, 2);   // four consecutive entries per lane in the dot phase
+            else if (g_bwd_variant == 6910) LAUNCH_FUSEDZ(0, 32, 1);  // streaming result stores
+            else if (g_bwd_variant == 6911) LAUNCH_FUSEDZ(0, 32, 2);
+            else LAUNCH_FUSED(0, 0);
+#undef LAUNCH_FUSED
+#undef LAUNCH_FUSEDZ
+            g_last_kernels = "fillBufferAligned+msda_bwd_enc_fused_d32";
+            return semidetr::launch_status("msda_bwd_enc_fused_d32");
         }
         if (g_bwd_variant == 697 && L * P == 16 && P == kPT && S < (1 << 23)) {
             // experiment: region scatter + gather in ONE launch, roles dealt out in groups of eight workgroups
@@ -573,6 +604,8 @@ int exp_launch_fast_backward(hipStream_t st, const float *grad_out, const float 
             else if (g_bwd_variant == 699) LAUNCH_REGW(512, 176, 8, 16, 24, 32, 4);   // same LDS, register budget of two
             else if (g_bwd_variant == 6981) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 4);    // walk unrolled by 4
             else if (g_bwd_variant == 6982) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 16);   // ... by 16
+            else if (g_bwd_variant == 6983) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 108);  // b128 entry reads, next batch prefetched
+            else if (g_bwd_variant == 6984) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 104);  // same, batches of 4
             else if (small) LAUNCH_REG(512, 208, 8, 16, 24, 32);
             else LAUNCH_REG(1024, 384, 16, 16, 32, 32);
 #undef LAUNCH_REG

@@ -22,23 +22,28 @@
 // NT threads; kRegQ queries per pass; region = RTH x RTW pixels of the finest level; WH x WW window per sampling level.
 // Two configurations are instantiated: <1024, 384, 16, 16, 32, 32> (one workgroup per CU) and <512, 208, 8, 16, 24, 32>
 // (two per CU: the phases of one hide the barriers of the other).
-template <int NT, int kRegQ, int WH, int WW>
+template <int NT, int kRegQ, int WH, int WW, int FUSE = 0>
 constexpr size_t reg_lds_bytes()
 {
-    return (size_t)(kRegQ * kPT * 4 + 8) * 8 + (size_t)kRegQ * kD * 4 + (size_t)2 * WH * WW * 4 + (size_t)kRegQ * 4 +
-           8 * 4 + (NT / 64) * 4 + 4 * kMaxLevels * 4 + 64;
+    return (size_t)(kRegQ * kPT * 4 + 8) * 8 + (FUSE ? (size_t)(kRegQ * kPT * 4 + 8) * 4 : 0) + (size_t)kRegQ * kD * 4 +
+           (size_t)2 * WH * WW * 4 + (size_t)kRegQ * 4 + 8 * 4 + (NT / 64) * 4 + 4 * kMaxLevels * 4 + 64;
 }
 
-template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0, int WU = 8>
+// AID (experiments build only): timing aids, results wrong -- 1: no dot phase, 2: no row atomics, 4: no result stores,
+// 8: dot phase without its global loads, 16: dot phase without its LDS reads
+template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0, int WU = 8, int FUSE = 0, int AID = 0>
 __device__ __forceinline__ void reg_scatter_body(
     const int b, float4 *smem, const float *__restrict__ gout, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue,
+    const float *__restrict__ value = nullptr)
 {
     constexpr int kWR = WH * WW, kNE = kRegQ * kPT * 4, SPT = (kRegQ * kPT + NT - 1) / NT, KC = (kWR + NT - 1) / NT;
     static_assert(kRegQ <= 512 && kWR <= (1 << 14), "entry packing: 9 bits query slot (x 128), 14 bits window row, sign bit = last");
     float2 *entries = reinterpret_cast<float2 *>(smem);   // [kNE + 8] front: bucketed {weight, last << 31 | window row << 16 | slot << 7};
                                                           // back: misses {weight, slot << 23 | pixel index}
-    float *gtile = reinterpret_cast<float *>(entries + kNE + 8);          // [kRegQ * kD] grad_out rows of the region's queries
+    // FUSE: [kNE + 8] <grad_out row, value row> of every entry (dot phase -> combine), same indexing as `entries`
+    float *dvals = reinterpret_cast<float *>(entries + kNE + 8);
+    float *gtile = dvals + (FUSE ? kNE + 8 : 0);                          // [kRegQ * kD] grad_out rows of the region's queries
     int *cnt = reinterpret_cast<int *>(gtile + kRegQ * kD);
     int *start = cnt + kWR;
     int *qlist = start + kWR;                                             // [kRegQ] query index of every slot
@@ -110,6 +115,9 @@ __device__ __forceinline__ void reg_scatter_body(
             int qs[SPT];
             auto srow_of = [&](int q) { return ((int64_t)n * Lq + q) * M + m; };      // recomputed: two registers fewer per sample
             float sm_max[SPT], sm_inv[SPT];
+            float dotsum[SPT];               // FUSE + fused prologue: sum over the levels of a_k * d/d a_k (softmax backward)
+#pragma unroll
+            for (int sp = 0; sp < SPT; ++sp) dotsum[sp] = 0.f;
 #pragma unroll
             for (int sp = 0; sp < SPT; ++sp) {
                 const int sidx = tid + sp * NT, i = sidx / P, p = sidx - i * P;
@@ -178,16 +186,14 @@ __device__ __forceinline__ void reg_scatter_body(
                 int *stats = stats2[l & 1];
                 if (tid < 4) stats[tid] = 0;
                 for (int k = tid; k < kWR; k += NT) cnt[k] = 0;
-                // ---- this thread's sample geometry: per corner weight, window row (or -1: miss, -2: no corner)
-                float cw[SPT][4];
-                int wrow[SPT][4], rank[SPT][4], pixb[SPT];      // pixb: pixel index of the top-left corner (misses only)
-                // every global load of the level first, unconditionally (an empty slot reads slot 0's row) instead of four
-                // serial load -> test -> load round trips.  The wait that follows also drains the wave's row atomics of the
-                // previous level (28 % of wave 0's cycles in the instrumented build); loading all levels before the level loop
-                // and forcing them to arrive there removes that wait (geometry 28 -> 4 %, count 18 -> 5 %) but the time moves
-                // into the walk (37 -> 51 %) and the next region's set-up (9 -> 23 %): 449 us either way -- what the waves wait
-                // for is the atomic path itself, wherever the wait is placed
+                // ---- this thread's sample geometry, kept compact (the registers live across every phase of the level):
+                //      bilinear fractions + attention, window index of the top-left corner, its pixel, and per corner one
+                //      "exists" bit (0..3) and one "inside the window" bit (4..7); corner weights and window rows are
+                //      recomputed where they are used
+                int s_wi[SPT], s_pix[SPT], s_fl[SPT], rank[SPT][4];
                 float gx[SPT], gy[SPT], ga[SPT];
+                float s_lw[SPT], s_lh[SPT], s_a[SPT];      // FUSE: bilinear fractions and attention of the thread's samples
+                const int base_pix = st + y0 * W + x0;     // window row r -> pixel base_pix + (r / WW) * W + r % WW
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
                     const int k = l * P + (tid + sp * NT) % P, qq = qs[sp] >= 0 ? qs[sp] : qlist[0];
@@ -213,22 +219,25 @@ __device__ __forceinline__ void reg_scatter_body(
                                     if (off[cidx] >= 0 && io.masked(n, st + h0 * W + w0 + (cidx & 1) + (cidx >> 1) * W)) off[cidx] = -1;
                         }
                     }
+                    s_lw[sp] = lw;
+                    s_lh[sp] = lh;
+                    s_a[sp] = a;
                     const int wy = h0 - y0, wx = w0 - x0;
                     const bool in_y0 = (unsigned)wy < (unsigned)WH, in_y1 = (unsigned)(wy + 1) < (unsigned)WH;
                     const bool in_x0 = (unsigned)wx < (unsigned)WW, in_x1 = (unsigned)(wx + 1) < (unsigned)WW;
-                    const int wi = wy * WW + wx;
-                    const float hh = 1.f - lh, hwt = 1.f - lw;
-                    const float cwv[4] = {hh * hwt * a, hh * lw * a, lh * hwt * a, lh * lw * a};
-                    const bool inw[4] = {in_y0 && in_x0, in_y0 && in_x1, in_y1 && in_x0, in_y1 && in_x1};
-                    const int wr[4] = {wi, wi + 1, wi + WW, wi + WW + 1};
-#pragma unroll
-                    for (int cidx = 0; cidx < 4; ++cidx) {
-                        cw[sp][cidx] = cwv[cidx];
-                        wrow[sp][cidx] = off[cidx] < 0 ? -2 : (inw[cidx] ? wr[cidx] : -1);
-                        rank[sp][cidx] = 0;
-                    }
-                    pixb[sp] = st + h0 * W + w0;          // a corner that exists (wrow != -2) is this + (c & 1) + (c >> 1) * W
+                    s_wi[sp] = wy * WW + wx;
+                    s_pix[sp] = st + h0 * W + w0;         // a corner that exists is this + (c & 1) + (c >> 1) * W
+                    s_fl[sp] = (off[0] >= 0 ? 1 : 0) | (off[1] >= 0 ? 2 : 0) | (off[2] >= 0 ? 4 : 0) | (off[3] >= 0 ? 8 : 0) |
+                               (in_y0 && in_x0 ? 16 : 0) | (in_y0 && in_x1 ? 32 : 0) | (in_y1 && in_x0 ? 64 : 0) |
+                               (in_y1 && in_x1 ? 128 : 0);
                 }
+                auto corner_w = [&](int sp, float (&cwv)[4]) {
+                    const float lw = s_lw[sp], lh = s_lh[sp], a = s_a[sp], hh = 1.f - lh, hwt = 1.f - lw;
+                    cwv[0] = hh * hwt * a;
+                    cwv[1] = hh * lw * a;
+                    cwv[2] = lh * hwt * a;
+                    cwv[3] = lh * lw * a;
+                };
                 lap(6);              // 6: sample geometry (global loads of sampling_loc / attn_weight)
                 __syncthreads();                  // counters zeroed, previous level's walk finished
                 lap(1);              // 1: waiting for the other waves' walk of the previous level
@@ -236,12 +245,21 @@ __device__ __forceinline__ void reg_scatter_body(
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
                     const int i = (tid + sp * NT) / P;
+                    float cwv[4];
+                    corner_w(sp, cwv);
 #pragma unroll
                     for (int cidx = 0; cidx < 4; ++cidx) {
-                        if (wrow[sp][cidx] >= 0) rank[sp][cidx] = atomicAdd(&cnt[wrow[sp][cidx]], 1);
-                        else if (wrow[sp][cidx] == -1)   // pixel index (< 2^23, checked by the launcher) + slot
-                            entries[kNE - 1 - atomicAdd(&stats[1], 1)] = make_float2(
-                                cw[sp][cidx], __int_as_float((int)(((unsigned)i << 23) | (unsigned)(pixb[sp] + (cidx & 1) + (cidx >> 1) * W))));
+                        const int wr = s_wi[sp] + (cidx & 1) + (cidx >> 1) * WW;
+                        rank[sp][cidx] = -1;
+                        if (!(s_fl[sp] & (1 << cidx))) continue;          // corner outside the level (or masked)
+                        if (s_fl[sp] & (16 << cidx)) {
+                            rank[sp][cidx] = atomicAdd(&cnt[wr], 1);
+                        } else {                          // pixel index (< 2^23, checked by the launcher) + slot
+                            const int at = kNE - 1 - atomicAdd(&stats[1], 1);
+                            entries[at] = make_float2(
+                                cwv[cidx], __int_as_float((int)(((unsigned)i << 23) | (unsigned)(s_pix[sp] + (cidx & 1) + (cidx >> 1) * W))));
+                            rank[sp][cidx] = at;          // FUSE: where the combine step finds this corner's dot product
+                        }
                     }
                 }
                 __syncthreads();
@@ -279,16 +297,100 @@ __device__ __forceinline__ void reg_scatter_body(
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
                     const int i = (tid + sp * NT) / P;
+                    float cwv[4];
+                    corner_w(sp, cwv);
 #pragma unroll
                     for (int cidx = 0; cidx < 4; ++cidx) {
-                        const int wr = wrow[sp][cidx];
-                        if (wr >= 0)
-                            entries[start[wr] + rank[sp][cidx]] = make_float2(
-                                cw[sp][cidx], __int_as_float((rank[sp][cidx] == cnt[wr] - 1 ? (int)0x80000000 : 0) | (wr << 16) | (i << 7)));
+                        const int wr = s_wi[sp] + (cidx & 1) + (cidx >> 1) * WW;
+                        if ((s_fl[sp] & (17 << cidx)) == (17 << cidx)) {      // exists and inside the window
+                            const int at = start[wr] + rank[sp][cidx];
+                            entries[at] = make_float2(
+                                cwv[cidx], __int_as_float((rank[sp][cidx] == cnt[wr] - 1 ? (int)0x80000000 : 0) | (wr << 16) | (i << 7)));
+                            rank[sp][cidx] = at;
+                        }
                     }
                 }
                 __syncthreads();
                 lap(4);              // 4: fill
+                if constexpr (FUSE) {
+                    // ---- dot phase: d_e = <grad_out row of the entry's query, value row of its corner> for EVERY entry, one
+                    //      lane per entry.  The sorted list makes neighbouring lanes read the same value rows (L1 hits); the
+                    //      grad_out row comes from the LDS tile.  Eight 16-byte pieces per operand, the piece order rotated by
+                    //      the lane so that the ds_read_b128 of a lane group spread over the banks.  gtile holds channel
+                    //      j + 16 h at position 2 j + h, so the 32-byte piece u pairs with value channels 4u.. and 16 + 4u..
+                    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)n * S * M * kD, (unsigned)S * M * kD * 4u);
+                    const unsigned head_b = (unsigned)m * kD * 4u, row_b = (unsigned)rs * 4u;
+                    const char *gtb0 = reinterpret_cast<const char *>(gtile);
+                    const int total = stats[3], nitems = total + stats[1];
+                    const int nquads = FUSE == 2 ? (total + 3) >> 2 : 0;
+                    // FUSE == 2: a lane takes FOUR consecutive entries of the sorted list and reloads the value row only when
+                    // the row changes (runs average ~8 entries), misses keep one lane per entry
+                    for (int it = tid; it < ((AID & 1) ? 0 : nquads); it += NT) {
+                        const int e0 = 4 * it, e1 = min(e0 + 4, total);
+                        float4 va[4], vb[4];
+                        int prev = -1;
+#pragma unroll 1
+                        for (int e = e0; e < e1; ++e) {
+                            const int pk = __float_as_int(entries[e].y);
+                            const int wr = (pk >> 16) & 0x3fff;
+                            if (wr != prev) {
+                                const unsigned rowb = (unsigned)(base_pix + (wr / WW) * W + wr % WW) * row_b + head_b;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const unsigned u = (unsigned)(k + lane) & 3u;
+                                    va[k] = buf_ld4(vr, rowb + 16u * u);
+                                    vb[k] = buf_ld4(vr, rowb + 64u + 16u * u);
+                                }
+                                prev = wr;
+                            }
+                            const unsigned slotb = (unsigned)(pk & 0xff80);
+                            float acc = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const unsigned u = (unsigned)(k + lane) & 3u;
+                                const float4 ga = *reinterpret_cast<const float4 *>(gtb0 + slotb + 32u * u);
+                                const float4 gb = *reinterpret_cast<const float4 *>(gtb0 + slotb + 32u * u + 16u);
+                                acc += ga.x * va[k].x + ga.y * vb[k].x + ga.z * va[k].y + ga.w * vb[k].y;
+                                acc += gb.x * va[k].z + gb.y * vb[k].z + gb.z * va[k].w + gb.w * vb[k].w;
+                            }
+                            dvals[e] = acc;
+                        }
+                    }
+                    for (int it = tid + (FUSE == 2 ? total : 0); it < ((AID & 1) ? 0 : nitems); it += NT) {
+                        const bool front = it < total;
+                        const int e = front ? it : kNE - 1 - (it - total);
+                        const int pk = __float_as_int(entries[e].y);
+                        const int wr = (pk >> 16) & 0x3fff;
+                        const int pix = front ? base_pix + (wr / WW) * W + wr % WW : (pk & 0x7fffff);
+                        const unsigned slotb = front ? (unsigned)(pk & 0xff80) : (((unsigned)pk >> 23) << 7);
+                        const unsigned rowb = (unsigned)pix * row_b + head_b;
+                        float4 va[4], vb[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned u = (unsigned)(k + lane) & 3u;
+                            if (AID & 8) {
+                                va[k] = make_float4(1.f, 2.f, 3.f, __uint_as_float(rowb + u));
+                                vb[k] = va[k];
+                                continue;
+                            }
+                            va[k] = buf_ld4(vr, rowb + 16u * u);
+                            vb[k] = buf_ld4(vr, rowb + 64u + 16u * u);
+                        }
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned u = (unsigned)(k + lane) & 3u;
+                            const float4 ga = (AID & 16) ? make_float4(1.f, 2.f, 3.f, __uint_as_float(slotb + u))
+                                                         : *reinterpret_cast<const float4 *>(gtb0 + slotb + 32u * u);
+                            const float4 gb = (AID & 16) ? ga : *reinterpret_cast<const float4 *>(gtb0 + slotb + 32u * u + 16u);
+                            acc += ga.x * va[k].x + ga.y * vb[k].x + ga.z * va[k].y + ga.w * vb[k].y;
+                            acc += gb.x * va[k].z + gb.y * vb[k].z + gb.z * va[k].w + gb.w * vb[k].w;
+                        }
+                        dvals[e] = acc;
+                    }
+                    __syncthreads();
+                    lap(7);          // 7: dot phase
+                }
                 // ---- owner computes: 64 streams of 16 lanes (lane l = channels l and l+16) each walk an equal share of
                 //      the row-sorted entries, running row sum in two registers, one atomic pair per finished row
                 {
@@ -301,16 +403,22 @@ __device__ __forceinline__ void reg_scatter_body(
                     auto gq_of = [&](float y) { return *reinterpret_cast<const float2 *>(gtb + (__float_as_int(y) & 0xff80)); };
                     float *gvs = gvalue + ((int64_t)n * S * M + m) * kD + l16;
                     const int total = stats[3];
-                    const int lo = (int)((int64_t)total * sid / kStreams);
-                    const int hi = (int)((int64_t)total * (sid + 1) / kStreams);
+                    // WU >= 100: shares start on even entries (16-byte aligned: two entries per ds_read_b128, which moves twice
+                    // the bytes per LDS cycle of the ds_read2_b64 the compiler picks for single entries) and the entries of batch
+                    // i + 1 are requested before batch i is processed
+                    constexpr bool kPipe = WU >= 100;
+                    constexpr int WB = WU % 100;
+                    const int lo = kPipe ? ((int)((int64_t)total * sid / kStreams) & ~1) : (int)((int64_t)total * sid / kStreams);
+                    const int hi = kPipe ? (sid + 1 == kStreams ? total : ((int)((int64_t)total * (sid + 1) / kStreams) & ~1))
+                                         : (int)((int64_t)total * (sid + 1) / kStreams);
                     int cur = -1;           // row of the most recent entry whose sum is still open, or -1
                     float2 accv = make_float2(0.f, 0.f);
                     // window row -> pixel by arithmetic (a table lookup here costs an LDS round trip inside the divergent flush
                     // branch, with every stream of the wavefront waiting on it)
-                    const int base_pix = st + y0 * W + x0;
                     auto flush = [&](int rowi) {
                         if (DBG && l16 == 0) SEMIDETR_DBG_ADD(12 + (l < 4 ? l : 3), 1);      // flushed rows by sampling level
                         float *pr = gvs + (int64_t)(base_pix + (rowi / WW) * W + rowi % WW) * rs;
+                        if ((AID & 2) && accv.x != 1.2345e30f) return;
                         fp_atomic_add(pr, accv.x);
                         fp_atomic_add(pr + 16, accv.y);
                     };
@@ -326,6 +434,43 @@ __device__ __forceinline__ void reg_scatter_body(
                         }
                     };
                     int e = lo;
+                    if constexpr (kPipe) {
+                        const float4 *e4 = reinterpret_cast<const float4 *>(entries);
+                        float4 ea[WB / 2];
+#pragma unroll
+                        for (int u = 0; u < WB / 2; ++u) ea[u] = e4[(e >> 1) + u];        // (the list has 8 entries of slack)
+                        for (; e + WB <= hi; e += WB) {
+                            float2 gq[WB];
+#pragma unroll
+                            for (int u = 0; u < WB / 2; ++u) {
+                                gq[2 * u] = gq_of(ea[u].y);
+                                gq[2 * u + 1] = gq_of(ea[u].w);
+                            }
+                            float4 nx[WB / 2];
+#pragma unroll
+                            for (int u = 0; u < WB / 2; ++u) nx[u] = e4[min((e + WB) >> 1, (kNE + 8 - WB) >> 1) + u];
+#pragma unroll
+                            for (int u = 0; u < WB / 2; ++u) {
+                                step(make_float2(ea[u].x, ea[u].y), gq[2 * u]);
+                                step(make_float2(ea[u].z, ea[u].w), gq[2 * u + 1]);
+                            }
+#pragma unroll
+                            for (int u = 0; u < WB / 2; ++u) ea[u] = nx[u];
+                        }
+                        if (e < hi) {       // tail of < WB entries: ea holds them (and whatever follows them in the list)
+                            float2 en[WB], gq[WB];
+#pragma unroll
+                            for (int u = 0; u < WB / 2; ++u) {
+                                en[2 * u] = make_float2(ea[u].x, ea[u].y);
+                                en[2 * u + 1] = make_float2(ea[u].z, ea[u].w);
+                            }
+#pragma unroll
+                            for (int u = 0; u < WB; ++u) gq[u] = gq_of(e + u < hi ? en[u].y : en[0].y);
+#pragma unroll
+                            for (int u = 0; u < WB; ++u)
+                                if (e + u < hi) step(en[u], gq[u]);
+                        }
+                    } else {
                     for (; e + WU <= hi; e += WU) {
                         float2 en[WU], gq[WU];
 #pragma unroll
@@ -345,6 +490,7 @@ __device__ __forceinline__ void reg_scatter_body(
                         for (int u = 0; u < WU; ++u)
                             if (e + u < hi) step(en[u], gq[u]);
                     }
+                    }
                     if (cur >= 0) flush(cur);
                     // ---- misses: one row update per (sample, corner), as the plain kernel does
                     const int nmiss = stats[1];
@@ -359,6 +505,51 @@ __device__ __forceinline__ void reg_scatter_body(
                     if (DBG && tid == 0) SEMIDETR_DBG_ADD(10, nmiss);
                 }
                 lap(5);              // 5: walk + misses of wave 0 (the other waves' walk ends show up in the next lap 1)
+                if constexpr (FUSE) {
+                    // ---- combine: the two small gradients of the thread's samples from the four corner dot products
+                    //      (ms_deform_im2col_cuda.cuh:123-158 in dot-product form, as msda_bwd_gather_d32 computes them)
+#pragma unroll
+                    for (int sp = 0; sp < SPT; ++sp) {
+                        if (qs[sp] < 0) continue;
+                        float d[4];
+#pragma unroll
+                        for (int cidx = 0; cidx < 4; ++cidx) d[cidx] = rank[sp][cidx] >= 0 ? dvals[rank[sp][cidx]] : 0.f;
+                        const float lw = s_lw[sp], lh = s_lh[sp], a = s_a[sp];
+                        const float hh = 1.f - lh, hwt = 1.f - lw;
+                        const float pa = hh * hwt * d[0] + hh * lw * d[1] + lh * hwt * d[2] + lh * lw * d[3];
+                        const float px = a * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
+                        const float py = a * (hwt * (d[2] - d[0]) + lw * (d[3] - d[1]));
+                        const int k = l * P + (tid + sp * NT) % P;
+                        const int64_t nq = (int64_t)n * Lq + qs[sp], srow = nq * M + m;
+                        if ((AID & 4) && pa != 1.2345e30f) continue;
+                        if constexpr ((AID & 32) != 0 && !IO::kSoftmax) {      // aid: streaming stores
+                            st_stream2(io.gloc + (srow * LP + k) * 2, make_float2((float)W * px, (float)H * py));
+                            st_stream1(io.gattn + srow * LP + k, pa);
+                            continue;
+                        }
+                        io.store_xy(srow, nq, LP, k, l, P, H, W, (float)W * px, (float)H * py);
+                        io.store_attn_partial(srow, LP, k, pa);      // final for the reference contract; d/d a_k for the fused prologue
+                        dotsum[sp] += a * pa;
+                    }
+                    lap(8);          // 8: combine
+                }
+            }
+            if constexpr (FUSE && IO::kSoftmax) {
+                // fused prologue: softmax backward over the row, g_logit_k = a_k * (g_a_k - sum_j a_j g_a_j).  The L * P values
+                // of a row are spread over the levels of the loop above, so they were parked in the output and are finished here
+#pragma unroll
+                for (int sp = 0; sp < SPT; ++sp) {
+                    float dot = dotsum[sp];
+                    dot += dpp_mov<0xB1>(dot);       // the four points of a (query, head) row sit in one quad
+                    dot += dpp_mov<0x4E>(dot);
+                    if (qs[sp] < 0) continue;
+                    const int64_t srow = srow_of(qs[sp]);
+                    const int p = (tid + sp * NT) % P;
+                    for (int l = 0; l < L; ++l) {
+                        const float a = __expf(io.load_w(srow, LP, l * P + p) - sm_max[sp]) * sm_inv[sp];
+                        io.finish_attn(srow, LP, l * P + p, a, dot);
+                    }
+                }
             }
         }
     }
@@ -374,7 +565,28 @@ __global__ __launch_bounds__(NT, WPE) void msda_bwd_scatter_d32_reg(
                                                           regions_bound, gvalue);
 }
 
-// ONE launch for both halves of the encoder backward (second attempt, after msda_bwd_enc_merged): region-scatter
+#if SEMIDETR_EXPERIMENTS
+// EXPERIMENT (round 4, backward variants 6900-6911; measured and rejected): the WHOLE encoder backward in one
+// kernel -- the region scatter above plus the two small gradients (reg_scatter_body<..., FUSE>).  Once the (sample, corner)
+// pairs of a level are bucketed, their dot products <grad_out[query], value[corner]> take one pass with a lane per entry
+// (the grad_out rows are in LDS already, the sorted order turns the value-row loads into L1 hits), and the owner of a sample
+// combines its four corners (dvals) into d/d attention and d/d location: no msda_bwd_gather_d32 launch.  Parity-green, but at
+// bs 4 766 us against 737 us for gather + scatter: the dot pass costs 256 us (its 8 x 16-byte loads per entry are bound by
+// the L1 return path exactly like the gather's: 138 us; LDS reads with a two-way bank conflict 56 us), the piecewise result
+// stores 79 us; a lane per FOUR entries with reloads on row changes (FUSE == 2) 1070 us.  grad_value must be zero on entry.
+template <typename IO, int NT, int kRegQ, int RTH, int RTW, int WH, int WW, int DBG = 0, int WPE = 4, int WU = 8, int AID = 0, int FZ = 1>
+__global__ __launch_bounds__(NT, WPE) void msda_bwd_enc_fused_d32(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    reg_scatter_body<IO, NT, kRegQ, RTH, RTW, WH, WW, DBG, WU, FZ, AID>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L,
+                                                                   regions_bound, gvalue, value);
+}
+#endif
+
+#if SEMIDETR_EXPERIMENTS
+// EXPERIMENT (backward variant 697, slower).  ONE launch for both halves of the encoder backward (second attempt, after msda_bwd_enc_merged): region-scatter
 // workgroups (LDS / instruction issue / atomics) and pairs of gather blocks (vector-memory path) share the CUs.  Roles
 // are dealt out in GROUPS OF EIGHT consecutive workgroups -- consecutive workgroups go round robin to the 8 XCDs, so
 // "every period-th workgroup scatters" with an even period had put all scatter workgroups on two XCDs.
@@ -401,3 +613,4 @@ __global__ __launch_bounds__(512, 4) void msda_bwd_encreg_merged(
     gather_body<IO, KLP, 408, true>(vb, (int)threadIdx.x & 255, smem + half * half_f4, vb < gather_blocks, gout, value,
                                     shapes, starts, io, S, M, L, S, P, gather_bound);
 }
+#endif

@@ -235,6 +235,11 @@ class FlatDDP(torch.nn.Module):
                 self._bucket_need[b] += 1
         self._index = {id(p): i for i, p in enumerate(self.params)}
         self._avg = (dist.is_initialized() and dist.get_backend(process_group) == "nccl")
+        # opt-in timing of the collectives (bench.py --gpus N): when each bucket was launched / became complete on the
+        # compute stream's timeline, and how long the end of backward waited for them
+        self.profile = False
+        self._stamps, self._last_stamps = None, None
+        self._bitmap = None                          # find_unused_parameters: preallocated device tensor of the used-bitmap
         self._reset()
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad_ready) for p in self.params]
 
@@ -252,6 +257,7 @@ class FlatDDP(torch.nn.Module):
         self._next = 0
         self._pending = []
         self._callback_queued = False
+        self._stamps = None
 
     # -- the hook autograd calls after a parameter's gradient has been accumulated
     def _on_grad_ready(self, p):
@@ -273,13 +279,41 @@ class FlatDDP(torch.nn.Module):
             self._left[b] -= 1
         self._launch_ready()
 
+    def _stamp(self):
+        """A point on the compute stream's timeline (an event) for GPU arenas, the host clock otherwise (gloo on CPU)."""
+        if self.arena.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+        return time.perf_counter()
+
     def _launch_ready(self, force=False):
         nb = len(self.arena.buckets)
         while self._next < nb and (force or self._left[self._next] == 0):
             s, e = self.arena.buckets[self._next]
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            if self.profile:
+                if self._stamps is None:
+                    self._stamps = {"ready": [], "done": []}
+                self._stamps["ready"].append(self._stamp())
             self._pending.append(dist.all_reduce(self.arena.flat[s:e], op=op, group=self.group, async_op=True))
             self._next += 1
+
+    def comm_profile(self):
+        """Timing of the LAST synchronising backward (profile = True): per bucket the time from its launch to its
+        completion as seen by the compute stream, and `exposed_ms` = how long the compute stream stood waiting for
+        collectives after the last gradient was final.  Synchronises the device."""
+        st = self._last_stamps
+        if not st:
+            return None
+        if self.arena.flat.is_cuda:
+            torch.cuda.synchronize(self.arena.flat.device)
+            ms = lambda a, b: a.elapsed_time(b)                          # noqa: E731
+        else:
+            ms = lambda a, b: (b - a) * 1e3                              # noqa: E731
+        return {"bucket_ready_to_done_ms": [ms(r, d) for r, d in zip(st["ready"], st["done"])],
+                "exposed_ms": ms(st["enter"], st["exit"]), "buckets": len(st["ready"])}
 
     def _finalize(self):
         """End of backward: reduce what is left (unused parameters), wait, sums -> means.
@@ -308,13 +342,28 @@ class FlatDDP(torch.nn.Module):
                     v.copy_(p.grad)                  # accumulated outside the arena: bring it home, keep its content
                     p.grad = v
             self._launch_ready(force=True)
+            if self.profile and self._stamps is not None:
+                self._stamps["enter"] = self._stamp()
             if self.find_unused_parameters:          # every rank takes part, whether or not IT has unused parameters;
-                # issued AFTER the last bucket on every rank: collectives must be queued in the same order everywhere
-                bitmap = torch.tensor([1 if f else 0 for f in self._fired], dtype=torch.int32,
-                                      device=self.arena.flat.device)
+                # issued AFTER the last bucket on every rank: collectives must be queued in the same order everywhere.
+                # The bitmap lives in a preallocated device tensor fed from pinned host memory (no per-step
+                # device allocation, no pageable copy); like torch DDP's local_used_map it is only read
+                # back -- the one host sync of this path -- when some parameter of THIS rank had no gradient at all.
+                if self._bitmap is None:
+                    self._bitmap = torch.zeros(len(self.params), dtype=torch.int32, device=self.arena.flat.device)
+                bitmap = self._bitmap
+                host = torch.tensor(self._fired, dtype=torch.int32)
+                if bitmap.is_cuda:
+                    host = host.pin_memory()         # (torch's caching host allocator keeps the block until the copy is done)
+                bitmap.copy_(host, non_blocking=True)
                 bm_work = dist.all_reduce(bitmap, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             for w in self._pending:
                 w.wait()
+                if self.profile and self._stamps is not None:
+                    self._stamps["done"].append(self._stamp())
+            if self.profile and self._stamps is not None:
+                self._stamps["exit"] = self._stamp()
+                self._last_stamps = self._stamps
             if not self._avg:
                 self.arena.flat.div_(self.world)
             if bm_work is not None:

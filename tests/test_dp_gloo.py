@@ -317,14 +317,22 @@ def _bench_worker(rank, world, port, q):
             return w
         dist.all_reduce, dist.all_gather, dist.broadcast = counted, other(real_ag), other(real_bc)
         try:
+            ddp.profile = True                       # bench.py --gpus N: launch / completion stamps of every bucket
             for step in range(2):
                 ddp.arena.flat.fill_(float(rank + 1))
-                # the order bench.Workload.step uses: heads + decoder, encoder, backbone, finish
+                # the order bench.Workload.step uses: heads + decoder, encoder, backbone (step 1: in four slices, last layers
+                # first, as with --backbone-ms), finish
                 ddp.mark_ready(student.groups["heads"] + student.groups["decoder"])
                 ddp.mark_ready(student.groups["encoder"])
-                ddp.mark_ready(student.groups["backbone"])
+                bb = list(reversed(student.groups["backbone"]))
+                parts = 4 if step else 1
+                for i in range(parts):
+                    ddp.mark_ready(bb[len(bb) * i // parts:len(bb) * (i + 1) // parts])
                 ddp.finish()
                 assert torch.allclose(ddp.arena.flat, torch.full_like(ddp.arena.flat, (1 + world) / 2.0))
+                prof = ddp.comm_profile()            # exposed wait + per-bucket launch -> complete
+                assert prof["buckets"] == len(ddp.arena.buckets) == len(prof["bucket_ready_to_done_ms"]), prof
+                assert prof["exposed_ms"] >= 0.0 and all(x >= 0.0 for x in prof["bucket_ready_to_done_ms"]), prof
         finally:
             dist.all_reduce, dist.all_gather, dist.broadcast = real_ar, real_ag, real_bc
         assert calls["all_reduce"] == 2 * len(ddp.arena.buckets) and len(ddp.arena.buckets) <= 4, calls

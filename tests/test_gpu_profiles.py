@@ -1,4 +1,4 @@
-"""GPU: the committed traffic figures (profiles/r03_pmc_traffic.json, written by tools/measure_traffic.py) must belong to
+"""GPU: the committed traffic figures (profiles/r04_pmc_traffic.json, written by tools/measure_traffic.py) must belong to
 the kernels the library launches TODAY for those shapes -- a renamed or re-dispatched kernel would otherwise leave a stale
 `roofline.traffic` in the bench line (bench.py drops an entry whose kernel list differs, this test makes the staleness
 visible in the suite)."""
@@ -17,7 +17,7 @@ LEVELS = [(100, 167), (50, 84), (25, 42), (13, 21)]
 def test_traffic_json_matches_the_kernels_the_library_launches():
     import semi_detr_amd as sda
     import MultiScaleDeformableAttention as MSDA
-    pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
     lib = sda._lib.lib()
     dev = torch.device("cuda:0")
     shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)

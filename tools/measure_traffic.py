@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Measure the HBM-side traffic of the MSDA launches bench.py times and write profiles/r03_pmc_traffic.json.
+"""Measure the HBM-side traffic of the MSDA launches bench.py times and write profiles/r04_pmc_traffic.json.
 
 Run on the GPU box:   python tools/measure_traffic.py
 For each event group of the bench step (encoder / decoder, forward / backward, the batch sizes of the step) it runs
@@ -92,7 +92,7 @@ def main():
             raise SystemExit("%s: msda kernels in the trace the library did not report: %r" % (group, stray))
         res[group] = {"kernels": rep_f, "per_kernel": kernels, "hbm_bytes_corrected": int(total)}
         print(group, rep_f, "%.1f MB" % (total / 1e6), flush=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r03_pmc_traffic.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r04_pmc_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
 
 

@@ -13,7 +13,7 @@ buf = (ctypes.c_ulonglong * 16)()
 dev = torch.device("cuda:0")
 for io in ("locattn", "raw"):
     wl = bench.Workload(dev, 0, "coco10", io)
-    v, a = wl.t[("value", 4)], wl._args("enc", 4, wl.S)
+    v, a = wl.t[("value", 4)][0], wl._args("enc", 4, wl.S, 0)
     fn = MSDA.ms_deform_attn_fused_forward if io == "raw" else MSDA.ms_deform_attn_forward
     extra = () if io == "raw" else (64,)
     for _ in range(3):
@@ -30,7 +30,7 @@ for io in ("locattn", "raw"):
     n = max(buf[11], 1)
     print(io, "us/launch %.1f" % (e0.elapsed_time(e1) * 100), "patches/launch", buf[11] // 10,
           "cycles per patch: wait %.0f records %.0f gather %.0f" % (buf[8] / n, buf[9] / n, buf[10] / n))
-    go = wl.t[("enc_gout", 4)]
+    go = wl.t[("enc_gout", 4)][0]
     fb = MSDA.ms_deform_attn_fused_backward if io == "raw" else MSDA.ms_deform_attn_backward
     for _ in range(3):
         fb(v, wl.shapes, wl.starts, *a, go, *extra)
