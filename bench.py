@@ -256,8 +256,8 @@ class Workload:
                 fn(v, self.shapes, self.starts, *a, *im2col)
         name = f"msda_fwd_{kind}_bs{n}_Lq{lq}"
         self._timed(name, reps, self.alg_bytes(n, lq, False), run)
-        if name not in self.kernels:
-            self.kernels[name] = self.sda._lib.lib().semidetr_msda_last_kernels().decode().split("+")
+        # (every time: the encoder forward's kernel is chosen from the data of the previous launches, the last call wins)
+        self.kernels[name] = self.sda._lib.lib().semidetr_msda_last_kernels().decode().split("+")
 
     def _bwd(self, kind, n, lq, reps):
         import MultiScaleDeformableAttention as MSDA
@@ -771,6 +771,54 @@ def cpu_baseline(wl=None):
             "min_max_s": spread}
 
 
+def forward_policy_bench(dev, iters=24, nsets=4):
+    """Encoder self-attention forward at bs 4 (the step's dominant launch) by how far the samples reach: sigma = 1 / 2 / 4 px of
+    the sampled level, rotated input sets, under the three policies of semidetr_msda_set_forward_policy.  `adaptive` is
+    timed after the dispatcher has seen the data (a few synchronised launches); it must sit on the faster kernel's time."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd as sda
+    shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h, (torch.arange(w, device=dev) + 0.5) / w,
+                                                indexing="ij"), -1).flip(-1).reshape(-1, 2) for h, w in LEVELS])
+    n, res = 4, {}
+    g = torch.Generator(device=dev).manual_seed(99)
+    for sigma in (1.0, 2.0, 4.0):
+        inv = torch.tensor([[sigma / w, sigma / h] for h, w in LEVELS], device=dev).view(1, 1, 1, L, 1, 2)
+        sets = []
+        for _ in range(nsets):
+            a = torch.rand(n, S, M, L, P, generator=g, device=dev) + 1e-5
+            sets.append((torch.rand(n, S, M, D, generator=g, device=dev) * 0.01,
+                         (ref.view(1, S, 1, 1, 1, 2) + torch.randn(n, S, M, L, P, 2, generator=g, device=dev) * inv).contiguous(),
+                         (a / a.sum((-1, -2), keepdim=True)).contiguous()))
+        row = {}
+        for policy in ("patch", "window", "adaptive"):
+            sda._lib.set_forward_policy(policy)
+            for i in range(6):                   # warm-up; synchronised, so that the adaptive dispatcher sees the counts
+                v, lo, at = sets[i % nsets]
+                MSDA.ms_deform_attn_forward(v, shapes, starts, lo, at, 64)
+                torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(iters):
+                v, lo, at = sets[i % nsets]
+                MSDA.ms_deform_attn_forward(v, shapes, starts, lo, at, 64)
+            e1.record()
+            torch.cuda.synchronize()
+            row[policy + "_us"] = e0.elapsed_time(e1) * 1e3 / iters
+            row[policy + "_kernel"] = sda._lib.lib().semidetr_msda_last_kernels().decode()
+        row["far_fraction"] = sda._lib.forward_policy_state()["far_fraction"]
+        row["adaptive_vs_patch"] = row["adaptive_us"] / row["patch_us"]
+        row["adaptive_frac_hbm_peak"] = msda_alg_bytes(n, S, False) / (row["adaptive_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        res["sigma_%g_px" % sigma] = row
+        del sets
+    sda._lib.set_forward_policy("adaptive")
+    res["what"] = ("msda forward, encoder self-attention, bs 4, Lq = S = 22223, %d rotated input sets, %d launches per timing; "
+                   "far_fraction = share of level >= 1 samples further than 4 px from their query's centre, as the kernels "
+                   "count it for the dispatcher" % (nsets, iters))
+    return res
+
+
 def comm_summary(ddp, stamps):
     """exposed communication + per-bucket latency of the timed steps (FlatDDP.profile), see `collectives.note`."""
     prof = []
@@ -834,6 +882,9 @@ def main():
                          "backward stands in for the ResNet-50 backward the step omits, so the backbone's buckets overlap with "
                          "something (realistic); 0 = pessimistic.  The sleep is subtracted from nothing: ms_per_step includes it")
     ap.add_argument("--no-flavours", action="store_true", help="skip the short runs of the other step flavours")
+    ap.add_argument("--forward-policy", default="adaptive", choices=["adaptive", "patch", "window"],
+                    help="encoder self-attention forward kernel (include/semidetr_hip.h: semidetr_msda_set_forward_policy); "
+                         "adaptive = the library's default, chosen from how far the samples of the previous launches reached")
     ap.add_argument("--input-sets", type=int, default=ROT,
                     help="distinct input sets per MSDA group, taken in turn by the six layers of a pass (default 6: every launch "
                          "reads its inputs from HBM; 1 = the rounds 1-3 methodology, one set replayed -- the 91 MB value map of a "
@@ -853,6 +904,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     wl = Workload(dev, seed=1234 + rank, recipe=args.recipe, io=args.io, input_sets=args.input_sets)
+    wl.sda._lib.set_forward_policy(args.forward_policy)
     ipg = wl.images_per_gpu
     ddp = None
     if world > 1:
@@ -932,10 +984,12 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_JSON)))
             except (OSError, ValueError):
                 return None, None
-            e = pmc.get(group)
-            if not e or sorted(e.get("kernels", [])) != sorted(wl.kernels.get(group, [])):
-                return None, None
-            return e.get("hbm_bytes_corrected"), "profiles/" + PMC_JSON + " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, tools/measure_traffic.py)"
+            for key in (group, group + "_window"):      # the encoder forward has one entry per kernel
+                e = pmc.get(key)
+                if e and sorted(e.get("kernels", [])) == sorted(wl.kernels.get(group, [])):
+                    return e.get("hbm_bytes_corrected"), ("profiles/" + PMC_JSON + ":" + key +
+                                                          " (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, tools/measure_traffic.py)")
+            return None, None
 
         def roofline_of(group):
             g = msda[group]
@@ -974,7 +1028,7 @@ def main():
                                    % ({"coco10": "COCO-10% (BASELINE.json configs[2]/[3])", "full": "COCO-Full (BASELINE.json configs[4])"}[args.recipe],
                                       wl.n_sup, wl.n_unsup, wl.S, wl.L, wl.S, wl.n_match, wl.n_params),
                        "recipe": args.recipe, "io": args.io, "images_per_gpu": ipg, "reuse_encoder": bool(args.reuse_encoder),
-                       "backbone_ms": args.backbone_ms, "input_sets_per_group": wl.rot,
+                       "backbone_ms": args.backbone_ms, "input_sets_per_group": wl.rot, "forward_policy": args.forward_policy,
                        "parallelism": "dp%d image-sharded, FlatDDP bucketed grad all-reduce of %d fp32 over RCCL" % (world, GRAD_ELEMS)
                        if world > 1 else "single GPU"},
             "roofline": roofline_of(dom_name),
@@ -995,6 +1049,7 @@ def main():
                             "corner_bytes_per_launch": corner_bytes, "device_clock_mhz_reported": clock_mhz},
             "rooflines_all_msda_groups": {k: {"frac_hbm_peak": roofline_of(k)["frac"], "avg_launch_us": roofline_of(k)["avg_launch_us"],
                                               "kernels": wl.kernels.get(k, [])} for k in sorted(msda)},
+            "forward_policy": wl.sda._lib.forward_policy_state(),      # encoder forward kernel choice after the timed steps
             "breakdown_ms_per_step": {k: v["ms"] / args.steps for k, v in sorted(stats.items())},
             "group_gbs": {k: v["bytes"] * v["launches"] / (v["ms"] * 1e-3) / 1e9 for k, v in sorted(stats.items())
                           if v["bytes"]},
@@ -1044,6 +1099,7 @@ def main():
                                                                            if nbytes_c else None)
                 out["microbench_cold_%s_frac_measured_counter_bytes" % leg] = (
                     nbytes_c / (c["us"] * 1e-6) / (mb["hbm_stream_measured_gbs"] * 1e9) if nbytes_c else None)
+            out["encoder_forward_by_sample_spread"] = forward_policy_bench(dev)
             out["module_fused_prologue"] = module_bench(dev)
             out["warmup_stage"] = warmup_stage_bench(dev)
         if world == 1 and not args.no_flavours and args.recipe == "coco10" and args.io == "locattn" and not args.reuse_encoder:

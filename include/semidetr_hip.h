@@ -4,7 +4,8 @@
  * Drop-in boundary: plain pointers + sizes, no torch types.  All pointers are DEVICE pointers unless
  * the parameter is documented as host.  `stream` is a hipStream_t passed as void* (NULL = the null
  * stream).  Every call is asynchronous on `stream`, keeps no global state between calls (apart from a
- * thread-local last-error string) and is re-entrant.  Return value: 0 on success, otherwise a
+ * thread-local last-error string and the per-device forward-kernel choice documented at
+ * semidetr_msda_set_forward_policy) and is re-entrant.  Return value: 0 on success, otherwise a
  * SEMIDETR_E_* code (negative: argument/precondition error detected on the host; positive: the
  * hipError_t returned by the launch).  semidetr_last_error() gives the message for the calling thread.
  *
@@ -25,7 +26,7 @@ extern "C" {
 #define SEMIDETR_E_TOOLARGE (-2)    /* an index would overflow the 32-bit arithmetic used on device  */
 #define SEMIDETR_E_NODEVICE (-3)    /* no HIP device available                                        */
 
-#define SEMIDETR_ABI_VERSION 4
+#define SEMIDETR_ABI_VERSION 5
 
 int semidetr_abi_version(void);
 const char *semidetr_last_error(void);
@@ -120,6 +121,25 @@ int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const 
                                      int spatial_size, int num_heads, int channels, int num_levels,
                                      int num_query, int num_point, int flags, float *grad_value,
                                      float *grad_sampling_offsets, float *grad_attn_logits);
+
+/* ---------------------------------------------------------------------------------------------
+ * Which kernel runs the encoder self-attention FORWARD (SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, four levels, no
+ * padding mask, batch >= 2).  The reference has one kernel for everything (ms_deform_im2col_cuda.cuh:237-299); here two
+ * produce the same results at different speeds depending on how far the learned offsets reach:
+ *   patch kernel   -- 4 x 8 query patches, every corner row through the vector-memory path; insensitive to the offsets
+ *   window kernel  -- 16 x 16 regions, the coarse levels' corner rows from LDS windows +- 4 px around the region;
+ *                     8-14 % faster while the samples stay inside, slower once ~20 % of them leave
+ * policy 0 (default, adaptive): both kernels count, in a few workgroups, the share of samples further than 4 px from their
+ *   query's pixel centre; launch k's count reaches the host through mapped pinned memory when launch k + 1 starts (no copy
+ *   command, no synchronisation) and the NEXT dispatch on that device moves between the kernels with hysteresis (to the
+ *   window kernel below 12 %, back above 17 %).  State is per device; launches inside a stream capture keep the kernel of
+ *   the moment and count nothing.
+ * policy 1: always the patch kernel.   policy 2: the window kernel whenever it applies.   (Process-wide.)
+ * semidetr_msda_forward_policy_state: for the calling thread's current device -- the policy, the kernel the adaptive policy
+ *   stands on (0 patch, 1 window), the last far-sample fraction received (-1: none yet), the number of counts received.
+ * ------------------------------------------------------------------------------------------- */
+int semidetr_msda_set_forward_policy(int policy);
+int semidetr_msda_forward_policy_state(int *policy, int *mode, float *far_fraction, unsigned *updates);
 
 /* Names of the device kernels the LAST semidetr_msda_* call of the calling thread launched ("+"-separated, as the
  * profiler prints their base names), so that a benchmark reports what actually ran instead of a hand-kept table. */

@@ -39,6 +39,8 @@ SIGNATURES = {
     "semidetr_msda_fused_forward_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
     "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 3 + [c_int] * 8 + [c_void_p] * 3),
     "semidetr_msda_last_kernels": (ctypes.c_char_p, []),
+    "semidetr_msda_set_forward_policy": (c_int, [c_int]),
+    "semidetr_msda_forward_policy_state": (c_int, [c_void_p] * 4),
     "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
     "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "semidetr_lsap_solve": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 6),
@@ -96,6 +98,23 @@ def check(rc, what):
 def current_stream_ptr():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+FORWARD_POLICIES = {"adaptive": 0, "patch": 1, "window": 2}
+
+
+def set_forward_policy(policy):
+    """Which kernel runs the encoder self-attention forward: "adaptive" (default: chosen from how far the samples of the
+    previous launches reached), "patch" or "window" (include/semidetr_hip.h, semidetr_msda_set_forward_policy)."""
+    check(lib().semidetr_msda_set_forward_policy(FORWARD_POLICIES.get(policy, policy)), "semidetr_msda_set_forward_policy")
+
+
+def forward_policy_state():
+    """{'policy', 'mode' (0 patch / 1 window), 'far_fraction' (-1: no count received yet), 'updates'} of the current device."""
+    pol, mode, upd, frac = c_int(), c_int(), ctypes.c_uint(), ctypes.c_float()
+    check(lib().semidetr_msda_forward_policy_state(ctypes.byref(pol), ctypes.byref(mode), ctypes.byref(frac), ctypes.byref(upd)),
+          "semidetr_msda_forward_policy_state")
+    return {"policy": pol.value, "mode": mode.value, "far_fraction": frac.value, "updates": upd.value}
 
 
 def set_variant(fwd, bwd):

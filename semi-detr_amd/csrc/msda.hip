@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 #if SEMIDETR_EXPERIMENTS
@@ -250,10 +251,10 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 #include "msda_fast_experiments.h"   // windowed scatter, resident-level forward, 512-thread merged / cooperative-fill backward
 #endif
 #include "msda_region.h" // region-owned windowed scatter for encoder self-attention
+#include "msda_rw.h"     // region-window forward (product since round 4) / gather (experiments) for encoder self-attention
 #if SEMIDETR_EXPERIMENTS    // negative results kept as evidence: only in libsemidetr_hip_exp.so
 #include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
 #include "msda_lw.h"     // LDS-window forward for encoder self-attention
-#include "msda_rw.h"     // region-window forward / gather for encoder self-attention
 #include "msda_own.h"    // owner-computes grad_value for arbitrary query sets
 #endif
 
@@ -355,8 +356,81 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
     return SEMIDETR_OK;
 }
 
+// ---- which kernel runs the encoder self-attention forward: the patch kernel (msda_fwd_d32<1,4,408>) or the region-window
+//      kernel (msda_rw_d32, LDS windows).  The second is 8-14 % faster while the learned offsets keep the samples within
+//      ~4 px of their queries and slower once a fifth of them leave (profiles/r04_region_window_dispatch.txt), so the choice
+//      follows the DATA: both kernels count how far their samples reach (FwdStats, msda_fast.h), the count of launch k is
+//      handed to the host by the first thread of launch k + 1 through mapped pinned memory, and the dispatcher -- whenever it
+//      next gets here, it never waits -- moves between the kernels with hysteresis.  Per device; a mutex serialises the few
+//      host words.  semidetr_msda_set_forward_policy pins the choice (tests, A/B timing).
+constexpr float kFarToWindow = 0.12f;      // patch -> window when fewer than this share of the samples are far ...
+constexpr float kFarToPatch = 0.17f;       // ... window -> patch above this one (crossover measured at ~0.2, sigma 2.5 px)
+struct FwdAdapt {
+    unsigned *dev_cnt = nullptr;           // device words: {far, total, kind, -} x launch parity, [8] = publications so far
+    unsigned *pub_host = nullptr;          // mapped pinned memory {sequence, far, total, kind}
+    unsigned *pub_dev = nullptr;           // the same memory as the device sees it
+    unsigned launches = 0, seen_seq = 0, updates = 0;
+    int mode = 0;                          // 0 = patch kernel, 1 = region-window kernel
+    float last_frac = -1.f;
+    bool failed = false;                   // allocation failed once: stay with the patch kernel, silently
+};
+constexpr int kMaxDevices = 64;
+std::mutex g_adapt_mu;
+FwdAdapt g_adapt[kMaxDevices];
+std::atomic<int> g_fwd_policy{0};          // 0 adaptive, 1 always the patch kernel, 2 the window kernel whenever it applies
+
+// the launch's FwdStats and the kernel to use; called with the stream the launch goes to
+int fwd_adapt_next(hipStream_t st, bool allow_window, FwdStats &fs, bool &use_window)
+{
+    fs = FwdStats{nullptr, nullptr, nullptr, nullptr};
+    const int policy = g_fwd_policy.load(std::memory_order_relaxed);
+    use_window = allow_window && policy == 2;
+    if (policy != 0 || !allow_window) return SEMIDETR_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return SEMIDETR_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(g_adapt_mu);
+    FwdAdapt &a = g_adapt[dev];
+    if (!a.dev_cnt && !a.failed && !capturing) {       // first use on this device (never inside a stream capture)
+        void *h = nullptr, *d = nullptr, *c = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess &&
+            hipMalloc(&c, 64) == hipSuccess && hipMemset(c, 0, 64) == hipSuccess) {
+            std::fill_n(static_cast<unsigned *>(h), 16, 0u);
+            a.pub_host = static_cast<unsigned *>(h);
+            a.pub_dev = static_cast<unsigned *>(d);
+            a.dev_cnt = static_cast<unsigned *>(c);
+        } else {
+            (void)hipGetLastError();
+            a.failed = true;
+        }
+    }
+    if (a.dev_cnt) {
+        volatile unsigned *pub = a.pub_host;
+        const unsigned seq = pub[0];
+        if (seq != a.seen_seq) {                       // a finished launch's counts have arrived since the last look
+            const unsigned far = pub[1], total = pub[2];
+            if (pub[0] != seq || far > total) {        // caught between two records (the device writes 16 bytes at once,
+                                                       // so this is paranoia): look again at the next dispatch
+            } else if (total) {
+                a.seen_seq = seq;
+                a.last_frac = (float)far / (float)total;
+                ++a.updates;
+                if (a.mode == 0 && a.last_frac < kFarToWindow) a.mode = 1;
+                else if (a.mode == 1 && a.last_frac > kFarToPatch) a.mode = 0;
+            }
+        }
+        if (!capturing) {                              // a captured launch keeps the kernel of the moment and counts nothing
+            const unsigned par = a.launches++ & 1u;
+            fs = FwdStats{a.dev_cnt + 4 * par, a.dev_cnt + 4 * (1 - par), a.pub_dev, a.dev_cnt + 8};
+        }
+    }
+    use_window = a.mode == 1;
+    return SEMIDETR_OK;
+}
+
 // ---- product dispatch of the fast path (fp32, channels == 32), shared by the reference contract (LocAttnIO) and the
-//      fused prologue (RawIO).  No variant state: what runs is a function of the arguments only.
+//      fused prologue (RawIO).  Apart from the forward-kernel choice above, what runs is a function of the arguments only.
 template <typename IO>
 int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spatial_shapes,
                         const int64_t *level_start, const IO &io, int N, int S, int M, int L, int Lq, int P,
@@ -370,11 +444,33 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
     hipLaunchKernelGGL((msda_fwd_d32<SP, 4, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        (LDS), st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
     if (pixels) {
-        // encoder self-attention: 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual
-        // pyramid (ragged edges included); a workgroup takes patches slot, slot + hint, ... so any hint >= 1 is correct
+        // encoder self-attention.  The region-window kernel is built for num_point == 4 and four levels, takes no padding
+        // mask (its windows are staged from `value` as it is) and needs >= 2 images' worth of regions to fill the chip
+        // (one 512-thread workgroup per CU; at bs 1 it only pays below sigma ~1.7 px)
+        const bool window_ok = P == kPT && L == 4 && !io.has_mask() && N >= 2;
+        FwdStats fs;
+        bool use_window = false;
+        if (int rc = fwd_adapt_next(st, window_ok, fs, use_window)) return rc;
+        if (use_window) {
+            auto kern = &msda_rw_d32<IO, 512, 16, 16, -1, 4, 4, false, 0, 40>;
+            constexpr size_t wlds = rw_lds_bytes<512, 16, 16, -1, 4, 4>();
+            static_assert(wlds <= 160 * 1024, "region-window configuration does not fit the LDS");
+            if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
+            // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
+            // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
+            const int wbound = ((S * 3 / 4 + 255) / 256) * 9 / 8 + 2 * L;
+            SEMIDETR_REQUIRE((int64_t)N * wbound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(512), wlds, st, (const float *)nullptr, value,
+                               spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs);
+            g_last_kernels = "msda_rw_d32<forward>";
+            return semidetr::launch_status("msda_rw_d32<forward>");
+        }
+        // 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges
+        // included); a workgroup takes patches slot, slot + hint, ... so any hint >= 1 is correct
         const int bound = (S + 31) / 32 * 5 / 4 + 4 * L;
         SEMIDETR_REQUIRE((int64_t)N * bound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
-        LAUNCH_FWD(1, 408, bound, (size_t)32 * (L * P + 1) * 32);
+        hipLaunchKernelGGL((msda_fwd_d32<1, 4, 408, IO>), dim3((unsigned)((int64_t)N * bound * M)), dim3(256),
+                           (size_t)32 * (L * P + 1) * 32, st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, bound, out, fs);
         g_last_kernels = "msda_fwd_d32<1, 4, 408";
         return semidetr::launch_status("msda_fwd_d32<patch>");
     }
@@ -507,6 +603,27 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
 }  // namespace
 
 extern "C" const char *semidetr_msda_last_kernels(void) { return g_last_kernels; }
+
+extern "C" int semidetr_msda_set_forward_policy(int policy)
+{
+    SEMIDETR_REQUIRE(policy >= 0 && policy <= 2, SEMIDETR_E_BADARG, "msda_set_forward_policy: 0 adaptive, 1 patch kernel, 2 window kernel");
+    g_fwd_policy.store(policy, std::memory_order_relaxed);
+    return SEMIDETR_OK;
+}
+
+extern "C" int semidetr_msda_forward_policy_state(int *policy, int *mode, float *far_fraction, unsigned *updates)
+{
+    int dev = 0;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return semidetr::fail((int)e, "msda_forward_policy_state: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(g_adapt_mu);
+    const FwdAdapt &a = g_adapt[dev >= 0 && dev < kMaxDevices ? dev : 0];
+    if (policy) *policy = g_fwd_policy.load(std::memory_order_relaxed);
+    if (mode) *mode = a.mode;
+    if (far_fraction) *far_fraction = a.last_frac;
+    if (updates) *updates = a.updates;
+    return SEMIDETR_OK;
+}
 
 #if SEMIDETR_EXPERIMENTS
 // tuning aid: per-phase cycle counters of the instrumented kernels; reset = 1 zeroes them

@@ -52,7 +52,7 @@ struct LocAttnIO {
     float *gloc, *gattn;
     static constexpr bool kSoftmax = false;      // attn already holds probabilities
     __device__ __forceinline__ bool masked(int n, int pixel) const { (void)n; (void)pixel; return false; }
-    __device__ __forceinline__ bool has_mask() const { return false; }
+    __host__ __device__ __forceinline__ bool has_mask() const { return false; }
     __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
@@ -109,7 +109,7 @@ struct RawIO {
     unsigned ref_bytes;                          // size of `ref` (N * Lq * L * ref_dim floats): bound of its buffer resource
     static constexpr bool kSoftmax = true;       // load_w returns a raw logit; the kernel normalises the row
     __device__ __forceinline__ bool masked(int n, int pixel) const { return mask[(int64_t)n * S + pixel] != 0; }
-    __device__ __forceinline__ bool has_mask() const { return mask != nullptr; }
+    __host__ __device__ __forceinline__ bool has_mask() const { return mask != nullptr; }
     __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
@@ -429,11 +429,59 @@ __device__ __forceinline__ int patch_query(const Patch &p, int r)      // r-th q
     return (y < p.Hq && x < p.Wq) ? p.stq + y * p.Wq + x : -1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// How far the samples of an encoder self-attention launch reach -- the statistic the dispatcher picks the forward kernel by
+// (msda.hip: launch_fast_forward).  The region-window kernel (msda_rw.h) serves the corners from LDS windows placed +- 4 px
+// around a region: 8-14 % faster than the patch kernel while the learned offsets stay inside, slower once a fifth of the
+// samples leave (profiles/r04_region_window_dispatch.txt).  Both kernels therefore count, in a few sampled workgroups,
+//     far   = samples on levels >= 1 more than kFarPx pixels (of the sampled level) from their query's own pixel centre
+//     total = samples on levels >= 1
+// into a device-side counter pair; the NEXT launch's first thread hands the finished pair to the host through mapped pinned
+// memory (one plain 16-byte store: no PCIe atomics, no fence, no copy command, no synchronisation), where the dispatcher reads it
+// when it gets there.  All pointers null: nothing is counted (fixed policy, stream capture, allocation failure).
+// ---------------------------------------------------------------------------------------------
+constexpr float kFarPx = 4.0f;
+struct FwdStats {
+    unsigned *cur;      // {far, total, kind, -} this launch accumulates into
+    unsigned *prev;     // the words the previous launch accumulated: published, then cleared
+    unsigned *pub;      // mapped host memory: {sequence, far, total, kind}
+    unsigned *seq;      // device word: number of publications so far
+};
+__device__ __forceinline__ void fwd_stats_publish(const FwdStats &fs)
+{
+    const unsigned far = fs.prev[0], total = fs.prev[1], kind = fs.prev[2];
+    if (total) {
+        // ONE 16-byte store, no fence: a system-scope release here writes back and invalidates this XCD's whole L2 (measured:
+        // +10-15 us on a 270 us launch); the store reaches the host at the latest when this kernel ends, which is early enough
+        // for a dispatcher that only ever looks at finished launches.  The host takes a record whose sequence number is new.
+        const unsigned sq = fs.seq[0] + 1u;
+        fs.seq[0] = sq;
+        *reinterpret_cast<uint4 *>(fs.pub) = make_uint4(sq, far, total, kind);
+    }
+    fs.prev[0] = 0u;
+    fs.prev[1] = 0u;
+}
+// one wave's counts -> the launch's counter pair
+__device__ __forceinline__ void fwd_stats_add(const FwdStats &fs, unsigned far, unsigned total, unsigned kind)
+{
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        far += __shfl_xor(far, s, 64);
+        total += __shfl_xor(total, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && total) {
+        atomicAdd(fs.cur, far);
+        atomicAdd(fs.cur + 1, total);
+        fs.cur[2] = kind;
+    }
+}
+
 // SPLIT = number of 8-lane groups that share one (q) row; each takes samples k = part, part+SPLIT, ...
 template <int SPLIT, int UNROLL, int PATCH = 0, typename IO = LocAttnIO>
 __global__ __launch_bounds__(256) void msda_fwd_d32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
-    const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ out)
+    const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ out,
+    const FwdStats fs = FwdStats{nullptr, nullptr, nullptr, nullptr})
 {
     constexpr int RPB = 32 / SPLIT;   // query rows per workgroup
     extern __shared__ float4 smem[];
@@ -446,6 +494,12 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     constexpr int PH = PATCH / 100, PW = PATCH % 100;
     static_assert(PATCH == 0 || (PH * PW == RPB && SPLIT == 1), "a patch holds exactly the workgroup's rows");
     Patch pt = {0, 0, 0, 0, 0};
+    bool sampled = false;                 // this workgroup counts how far its samples reach (FwdStats)
+    if constexpr (PATCH != 0) {
+        if (fs.cur) {
+            sampled = (blockIdx.x & 255) == 1;
+        }
+    }
     // When L*P divides 256 a thread's samples s = tid, tid + 256, ... all have the same (level, point): its level's H, W,
     // start (three dependent int64 global loads per sample otherwise, in front of the coordinate arithmetic) are fetched once
     const bool fixed_k = (256 % LP) == 0;
@@ -459,7 +513,12 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
 #endif
     if (PATCH) {
         pt = find_patch<PH ? PH : 1, PW ? PW : 1>(tile, shapes, starts, L);
-        if (pt.Hq == 0) return;
+        if (pt.Hq == 0) {
+            // the launch's FIRST workgroup hands the previous launch's counts to the host when it is done: it started first,
+            // so this is nowhere near the launch's tail (at its start the few dependent loads delayed its CU's whole queue)
+            if (fs.cur && blockIdx.x == 0 && threadIdx.x == 0) fwd_stats_publish(fs);
+            return;
+        }
         __syncthreads();      // previous patch done with the LDS records
     }
 #if SEMIDETR_EXPERIMENTS
@@ -480,6 +539,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     // them (an empty slot reads query 0 of the image): the loads' latencies overlap, and the two softmax reduction chains
     // of the fused prologue (8 dependent DPP steps + exp + rcp each) interleave instead of running back to back -- the
     // record phase is the serial section of a workgroup, everything it waits for is paid by the gather phase behind it.
+    unsigned st_far = 0, st_total = 0;
     for (int s0 = threadIdx.x; s0 < RPB * LP; s0 += 512) {
         int rr[2], kk[2], qq[2];
         float x[2], y[2], raw[2];
@@ -513,6 +573,13 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
                 const int l = kk[u] / P;
                 const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
                 const int st = fixed_k ? stf : (int)starts[l];
+                if (PATCH != 0 && sampled && l >= 1) {      // (workgroup-uniform: one workgroup in 256 pays for this)
+                    constexpr int PW_ = PW ? PW : 1;
+                    const float cx = ((float)(pt.x0 + rr[u] % PW_) + 0.5f) / (float)pt.Wq;
+                    const float cy = ((float)(pt.y0 + rr[u] / PW_) + 0.5f) / (float)pt.Hq;
+                    st_total += 1u;
+                    st_far += (fabsf((x[u] - cx) * (float)W) > kFarPx || fabsf((y[u] - cy) * (float)H) > kFarPx) ? 1u : 0u;
+                }
                 float lw, lh;
                 if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                     const float hh = 1.f - lh, hw = 1.f - lw;
@@ -524,6 +591,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
             rec_w[rr[u] * LPP + kk[u]] = w;
         }
     }
+    if (PATCH != 0 && sampled) fwd_stats_add(fs, st_far, st_total, 1u);
     __syncthreads();
 #if SEMIDETR_EXPERIMENTS
     const unsigned long long tm2 = __builtin_readcyclecounter();

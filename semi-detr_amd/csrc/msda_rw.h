@@ -1,7 +1,9 @@
 // Encoder self-attention with the value rows served from REGION WINDOWS in LDS (fp32, D == 32, num_point == 4):
 // forward (msda_rw_d32<..., false>) and the gather half of the backward (<..., true>: grad_sampling_loc /
 // grad_attn_weight, optionally clearing grad_value for the scatter launch that follows).  Included by msda.hip after
-// msda_fast.h / msda_region.h.
+// msda_fast.h / msda_region.h.  PRODUCT since round 4: the forward instantiation <512 threads, 16 x 16 regions, level 0 through
+// global loads, margin 4> is what launch_fast_forward picks while the samples stay close to their queries (FwdStats); the
+// other configurations and the gather half are reachable from the experiments library only.
 //
 // Why.  The patch kernels (msda_fwd_d32<1,4,408>, msda_bwd_gather_d32) pull every corner row through the vector-memory
 // path: 4 x 22223 x 8 heads x 16 samples x 4 corners x 128 B = 5.8 GB per bs-4 launch at 64 B/clk/CU -- TA busy 80 %,
@@ -99,7 +101,7 @@ template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GA
 __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(      // 256-thread workgroups: two per CU
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int regions_bound, float *__restrict__ out,
-    float4 *__restrict__ zero, int64_t zero_n4)
+    float4 *__restrict__ zero, int64_t zero_n4, const FwdStats fs = FwdStats{nullptr, nullptr, nullptr, nullptr})
 {
     using Wn = RwWin<RTH, RTW, H0, HC, KL>;
     constexpr int P = kPT, KLP = KL * P, G = NT / 8, NPASS = (KLP + 7) / 8;
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     const int Lq = S, rs = M * kD;
     const int b = (int)blockIdx.x;
     unsigned long long tmark = DBG == 1 ? __builtin_readcyclecounter() : 0ull;
+    (void)tmark;
     auto lap = [&](int slot_) {
         if (DBG == 1 && tid == 0) {
             const unsigned long long now = __builtin_readcyclecounter();
@@ -131,6 +134,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     };
     const int m = (b % M + (b / M) / kRwHeadRun) % M;
     const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
+    // how far the samples reach, for the dispatcher's choice between this kernel and the patch kernel (FwdStats, msda_fast.h):
+    // one workgroup in 32 counts, the launch's first thread publishes the previous launch's pair
+    const bool sampled = !GATHER && fs.cur != nullptr && (b & 31) == 1;
+    unsigned st_far = 0, st_total = 0;
 
     if (GATHER && zero) {      // side job: clear grad_value, which the scatter launch that FOLLOWS accumulates into
         const int64_t per = (zero_n4 + gridDim.x - 1) / gridDim.x;
@@ -323,12 +330,28 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 float sum = 0.f;
 #pragma unroll
                 for (int p = 0; p < NPASS; ++p) {
-                    sa[p] = (j8 + 8 * p < KLP) ? expf(sa[p] - mx) : 0.f;
+                    sa[p] = (j8 + 8 * p < KLP) ? __expf(sa[p] - mx) : 0.f;      // as row_softmax: the kernels of one op agree
                     sum += sa[p];
                 }
                 sum = group8_sum(sum);
+                const float inv = fast_rcp(sum);
 #pragma unroll
-                for (int p = 0; p < NPASS; ++p) sa[p] = sa[p] / sum;
+                for (int p = 0; p < NPASS; ++p) sa[p] = sa[p] * inv;
+            }
+            if (sampled && round == 0 && q >= 0) {     // (workgroup-uniform branch; the first round's 64 queries are sample enough --
+                                                       //  counting in every round made the sampled workgroups the launch's stragglers)
+                int lq = 0;                        // the query's own level: levels tile [0, S) in order
+#pragma unroll
+                for (int l = 1; l < KL; ++l) lq = q >= sts[l] ? l : lq;
+                const int Wq = __shfl(r_W, lq, 64), Hq = __shfl(r_H, lq, 64), pix = q - __shfl(r_st, lq, 64);
+                const int qy = (int)(((float)pix + 0.5f) / (float)Wq), qx = pix - qy * Wq;      // pix < 2^23: exact
+                const float cx = ((float)qx + 0.5f) / (float)Wq, cy = ((float)qy + 0.5f) / (float)Hq;
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p)
+                    if (j8 + 8 * p < KLP && myl[p] >= 1) {
+                        st_total += 1u;
+                        st_far += (fabsf((sx[p] - cx) * (float)myW[p]) > kFarPx || fabsf((sy[p] - cy) * (float)myH[p]) > kFarPx) ? 1u : 0u;
+                    }
             }
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
@@ -616,4 +639,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         }
         if (DBG == 1 && tid == 0) SEMIDETR_DBG_ADD(11, 1);
     }
+    if (sampled) fwd_stats_add(fs, st_far, st_total, 2u);
+    // the launch's first workgroup hands the previous launch's counts to the host when it is done (see msda_fwd_d32)
+    if (!GATHER && fs.cur != nullptr && b == 0 && tid == 0) fwd_stats_publish(fs);
 }

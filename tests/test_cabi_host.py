@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/semidetr_hip.h but not exported"
     assert sorted(semi_detr_amd._lib.SIGNATURES) == names
-    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 4
+    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 5
     # the tuning / measurement entry points live ONLY in the experiments build (not in what ships)
     extra = _declared_functions("semidetr_hip_experiments.h")
     assert extra == sorted(semi_detr_amd._lib.EXPERIMENT_SIGNATURES) and len(extra) == 3
@@ -36,26 +36,30 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(exp, n), f"{n} missing from libsemidetr_hip_exp.so"
     for n in extra:
         assert not hasattr(handle, n), f"{n} must not be exported by the product library"
-    assert exp.semidetr_abi_version() == 4
+    assert exp.semidetr_abi_version() == 5
 
 
 def test_product_code_object_holds_only_reachable_msda_kernels():
-    """the product library's MSDA code object = the kernels its dispatcher can reach (28: forward patch /
-    strips x 3 splits, generic, gather x 3, region scatter, 1024-thread merged level scatter x 2, strips backward x 2 -- each
-    for the reference contract and the fused prologue, + fp64 generic), none of the rejected experiments."""
+    """the product library's MSDA code object = the kernels its dispatcher can reach (30: forward patch /
+    strips x 3 splits, region-window forward (round 4), generic, gather x 3, region scatter, 1024-thread merged level scatter
+    x 2, strips backward x 2 -- each for the reference contract and the fused prologue, + fp64 generic), none of the
+    rejected experiments -- of msda_rw_d32 only the ONE forward configuration the dispatcher launches."""
     import subprocess
     csrc = os.path.join(ROOT, "semi-detr_amd", "csrc")
     syms = subprocess.run(["strings", "-a", os.path.join(csrc, "libsemidetr_hip.so")], capture_output=True, text=True).stdout
     kernels = set(re.findall(r"_ZN12_GLOBAL__N_1\d+(msda_[a-z0-9_]+)I[^\n]*?\.kd", syms))
     names = set(re.findall(r"(_ZN12_GLOBAL__N_1\d+msda_[A-Za-z0-9_]+)\.kd", syms))
-    assert 20 <= len(names) <= 30, sorted(names)
+    assert 20 <= len(names) <= 32, sorted(names)
     for banned in ("msda_bwd_dest_d32", "msda_fwd_d32_lw", "msda_fwd_d32_res", "msda_bwd_enc_merged", "msda_bwd_encreg_merged",
-                   "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "msda_rw_d32", "stream_kernel", "msda_bwd_own_merged",
-                   "msda_fwd_d32_ws", "msda_bwd_lvl_mergedI"):
+                   "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "stream_kernel", "msda_bwd_own_merged",
+                   "msda_fwd_d32_ws", "msda_bwd_lvl_mergedI", "msda_bwd_enc_fused_d32"):
         assert banned not in syms, banned
+    rw = sorted(n for n in names if "msda_rw_d32" in n)       # LocAttnIO + RawIO instantiation of <512, 16, 16, -1, 4, 4, forward>
+    assert len(rw) == 2 and all("Li512ELi16ELi16ELin1ELi4ELi4ELb0E" in n for n in rw), rw
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(csrc, "libsemidetr_hip.so")],
                                           capture_output=True, text=True).stdout
-    assert kernels >= {"msda_fwd_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged_wide", "msda_bwd_d32"}
+    assert kernels >= {"msda_fwd_d32", "msda_rw_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged_wide",
+                       "msda_bwd_d32"}
 
 
 def test_host_side_argument_errors_need_no_gpu():
@@ -96,7 +100,7 @@ def test_compiled_front_end_is_the_reference_module_surface():
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd
     assert type(MSDA.ms_deform_attn_forward).__name__ == "builtin_function_or_method" or "pybind" in repr(MSDA.ms_deform_attn_forward)
-    assert semi_detr_amd.MultiScaleDeformableAttention._msda_ext.abi_version() == 4
+    assert semi_detr_amd.MultiScaleDeformableAttention._msda_ext.abi_version() == 5
     sh, ls = torch.tensor([[2, 3], [1, 2]]), torch.tensor([0, 6])
     assert MSDA.pyramid_check(sh, ls, 8) == 3
     assert MSDA.pyramid_check(sh, ls, 8) == 3                      # cache hit

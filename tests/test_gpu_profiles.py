@@ -25,9 +25,11 @@ def test_traffic_json_matches_the_kernels_the_library_launches():
     S, M, D, L, P = int((shapes[:, 0] * shapes[:, 1]).sum()), 8, 32, 4, 4
     checked = 0
     for group, entry in pmc.items():
-        m = re.fullmatch(r"msda_(fwd|bwd)_(enc|dec|micro)_bs(\d+)_Lq(\d+)(_cold)?", group)
+        m = re.fullmatch(r"msda_(fwd|bwd)_(enc|dec|micro)_bs(\d+)_Lq(\d+)(_cold|_window)?", group)
         if not m:
             continue
+        # the encoder forward has two kernels (include/semidetr_hip.h: semidetr_msda_set_forward_policy): one entry each
+        sda._lib.set_forward_policy("window" if m.group(5) == "_window" else "patch")
         direction, n, lq = m.group(1), int(m.group(3)), int(m.group(4))
         value = torch.rand(n, S, M, D, device=dev)
         loc = torch.rand(n, lq, M, L, P, 2, device=dev)
@@ -41,4 +43,5 @@ def test_traffic_json_matches_the_kernels_the_library_launches():
         assert entry["hbm_bytes_corrected"] > 0
         checked += 1
     torch.cuda.synchronize()
+    sda._lib.set_forward_policy("adaptive")
     assert checked >= 6

@@ -23,9 +23,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "traffic")
 GROUPS = [  # bench group name, probe arguments
-    ("msda_fwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "fwd"]),
+    ("msda_fwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "patch"]),
+    # the same launch through the region-window kernel (what the adaptive policy runs at this sample spread)
+    ("msda_fwd_enc_bs4_Lq22223_window", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "window"]),
     ("msda_bwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "bwd"]),
-    ("msda_fwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "fwd"]),
+    ("msda_fwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "fwd", "--policy", "patch"]),
     ("msda_bwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "bwd"]),
     ("msda_fwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "fwd"]),
     ("msda_bwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "bwd"]),

@@ -24,11 +24,15 @@ def main():
     ap.add_argument("--fvariant", type=int, default=None)
     ap.add_argument("--sigma", type=float, default=2.0, help="encoder sample spread in pixels")
     ap.add_argument("--print-kernels", action="store_true", help="print what the library says it launched (KERNELS=...)")
+    ap.add_argument("--policy", default="adaptive", choices=["adaptive", "patch", "window"],
+                    help="encoder forward kernel (semidetr_msda_set_forward_policy)")
+    ap.add_argument("--settle", type=int, default=0, help="synchronised warm-up launches (lets the adaptive forward policy see the data)")
     ap.add_argument("--cold", type=int, default=1, help="rotate this many distinct input sets (8 x 47 MB > the Infinity Cache)")
     a = ap.parse_args()
     import semi_detr_amd as sda
     import MultiScaleDeformableAttention as MSDA
     sda._lib.set_variant(a.variant if a.fvariant is None else a.fvariant, a.variant)
+    sda._lib.set_forward_policy(a.policy)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     S, M, D, L, P, LEVELS = bench.S, bench.M, bench.D, bench.L, bench.P, bench.LEVELS
@@ -69,6 +73,9 @@ def main():
             MSDA.ms_deform_attn_backward(v, shapes, starts, lo, at, go, 64)
         runs.append(("bwd", b_, True))
     for name, fn, bw in runs:
+        for _ in range(a.settle):
+            fn()
+            torch.cuda.synchronize()
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
