@@ -462,7 +462,7 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             SEMIDETR_REQUIRE((int64_t)N * wbound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
             hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(512), wlds, st, (const float *)nullptr, value,
                                spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs);
-            g_last_kernels = "msda_rw_d32<forward>";
+            g_last_kernels = "msda_rw_d32";
             return semidetr::launch_status("msda_rw_d32<forward>");
         }
         // 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges

@@ -105,7 +105,7 @@ int exp_launch_fast_forward(hipStream_t st, const float *value, const int64_t *s
     if (g_fwd_variant >= 700 && g_fwd_variant <= 709) {
         SEMIDETR_REQUIRE(pixels && P == kPT && (L == 4 || L == 5), SEMIDETR_E_BADARG,
                          "msda_forward: the region-window kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, 4 or 5 levels");
-        g_last_kernels = "msda_rw_d32<forward>";
+        g_last_kernels = "msda_rw_d32";
         if (L == 4)
             return launch_rw_cfg<IO, 4, false>(g_fwd_variant - 700, st, nullptr, value, spatial_shapes, level_start, io, N, S, M, out, nullptr, 0);
         return launch_rw_cfg<IO, 5, false>(0, st, nullptr, value, spatial_shapes, level_start, io, N, S, M, out, nullptr, 0);

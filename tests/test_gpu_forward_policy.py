@@ -63,7 +63,7 @@ def test_window_and_patch_forward_vs_oracle(shapes, N, mode):
     want = oracle.msda_forward(value, shp, loc, attn)
     tsh = _t(shp)
     args = (_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)
-    for policy, kernel in (("patch", "msda_fwd_d32<1, 4, 408"), ("window", "msda_rw_d32<forward>")):
+    for policy, kernel in (("patch", "msda_fwd_d32<1, 4, 408"), ("window", "msda_rw_d32")):
         sda._lib.set_forward_policy(policy)
         out = MSDA.ms_deform_attn_forward(*args)
         assert _last() == kernel, (policy, _last())
@@ -85,7 +85,7 @@ def test_window_forward_full_size_vs_oracle(io):
         out = MSDA.ms_deform_attn_forward(_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)
     else:
         out = MSDA.ms_deform_attn_fused_forward(_t(value), tsh, _starts(tsh), _t(ref), _t(off), _t(logits))
-    assert _last() == "msda_rw_d32<forward>"
+    assert _last() == "msda_rw_d32"
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6)
 
 
@@ -145,8 +145,8 @@ def test_adaptive_policy_follows_the_sample_spread():
     st1 = sda._lib.forward_policy_state()
     assert st1["updates"] > st0["updates"], (st0, st1)
     assert st1["mode"] == 1 and 0.0 <= st1["far_fraction"] < 0.12, st1
-    assert k_close[-1] == "msda_rw_d32<forward>", k_close
+    assert k_close[-1] == "msda_rw_d32", k_close
     k_far = run(6.0, 6)
     st2 = sda._lib.forward_policy_state()
     assert st2["mode"] == 0 and st2["far_fraction"] > 0.17, st2
-    assert k_far[0] == "msda_rw_d32<forward>" and k_far[-1] == "msda_fwd_d32<1, 4, 408", k_far
+    assert k_far[0] == "msda_rw_d32" and k_far[-1] == "msda_fwd_d32<1, 4, 408", k_far
