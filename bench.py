@@ -472,6 +472,9 @@ def microbench(dev, iters=200, warm=20):
     N, Lq, NSETS = 2, 300, 8
     sets = [_msda_case(dev, LEVELS, N, Lq, False)[:6] for _ in range(NSETS)]
     value, shapes, starts, loc, attn, gout = sets[0]
+    # ONE (spatial_shapes, level_start_index) pair for all sets, as a model has: the front end's cached level-table check is
+    # keyed on these tensors (and a table first seen inside a stream capture gets the assume-nothing kernels)
+    sets = [(v, shapes, starts, lo, at, go) for v, _, _, lo, at, go in sets]
     res = {}
     for name, fn in (("fwd", lambda: MSDA.ms_deform_attn_forward(value, shapes, starts, loc, attn, 64)),
                      ("bwd", lambda: MSDA.ms_deform_attn_backward(value, shapes, starts, loc, attn, gout, 64))):

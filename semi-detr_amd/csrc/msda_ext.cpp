@@ -111,6 +111,12 @@ int pyramid_check(const at::Tensor &shapes, const at::Tensor &starts, int64_t S)
     TORCH_CHECK(shapes.scalar_type() == at::kLong && starts.scalar_type() == at::kLong && shapes.dim() == 2 &&
                     shapes.size(1) == 2 && starts.numel() == shapes.size(0),
                 "pyramid_check: expected spatial_shapes (L,2) and level_start_index (L,) of dtype int64");
+    if (shapes.is_cuda()) {      // a table not seen before costs a device-to-host copy, which a stream capture does not allow:
+        // answer "nothing known" (the kernels that assume nothing) and do not cache it
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(shapes.device().index()).stream();
+        if (hipStreamIsCapturing(cur, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return 0;
+    }
     const at::Tensor hs = shapes.to(at::kCPU).contiguous(), hl = starts.to(at::kCPU).contiguous();
     const int64_t *ps = hs.data_ptr<int64_t>(), *pl = hl.data_ptr<int64_t>();
     int64_t sum = 0;
