@@ -1014,8 +1014,9 @@ def main():
         l1_peak = 256 * 64 * 2400e6 / 1e9
         # observed clock / TA busy fraction of this kernel: measured by tools/r04_fwd_ta_evidence.sh (rocprofv3 --pmc), read
         # from the committed summary rather than carried as constants
-        try:
-            ta_ev = json.load(open(os.path.join(ROOT, "profiles", TA_JSON)))
+        try:      # (one entry per forward kernel: the one this run's encoder forward launched)
+            ran = (wl.kernels.get("msda_fwd_enc_bs%d_Lq%d" % (wl.n_unsup, wl.S)) or ["msda_fwd_d32"])[0].split("<")[0]
+            ta_ev = json.load(open(os.path.join(ROOT, "profiles", TA_JSON)))[ran]
             obs_mhz, ta_frac = float(ta_ev["observed_clock_mhz"]), float(ta_ev["ta_busy_frac"])
         except (OSError, ValueError, KeyError, TypeError):
             ta_ev, obs_mhz, ta_frac = None, None, None

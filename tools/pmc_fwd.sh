@@ -6,6 +6,7 @@ i=0
 for set in "TA_BUSY_avr" "TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TCC_READ_REQ_sum" \
            "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
+  rm -rf $R/gpurun_out/pmcset_$i
   timeout -k 5 90 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcset_$i -- python $R/tools/msda_probe.py "$@" > $R/gpurun_out/pmcset_$i.log 2>&1 || tail -3 $R/gpurun_out/pmcset_$i.log
 done
 python - <<PY
