@@ -357,14 +357,14 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 }
 
 // ---- which kernel runs the encoder self-attention forward: the patch kernel (msda_fwd_d32<1,4,408>) or the region-window
-//      kernel (msda_rw_d32, LDS windows).  The second is 8-14 % faster while the learned offsets keep the samples within
-//      ~4 px of their queries and slower once a fifth of them leave (profiles/r04_region_window_dispatch.txt), so the choice
+//      kernel (msda_rw_d32, LDS windows).  The second is 7-17 % faster while the learned offsets keep most samples within
+//      a few pixels of their queries and slower once almost half of them are further than 4 px away (profiles/r04_region_window_dispatch.txt), so the choice
 //      follows the DATA: both kernels count how far their samples reach (FwdStats, msda_fast.h), the count of launch k is
 //      handed to the host by the first thread of launch k + 1 through mapped pinned memory, and the dispatcher -- whenever it
 //      next gets here, it never waits -- moves between the kernels with hysteresis.  Per device; a mutex serialises the few
 //      host words.  semidetr_msda_set_forward_policy pins the choice (tests, A/B timing).
-constexpr float kFarToWindow = 0.12f;      // patch -> window when fewer than this share of the samples are far ...
-constexpr float kFarToPatch = 0.17f;       // ... window -> patch above this one (crossover measured at ~0.2, sigma 2.5 px)
+constexpr float kFarToWindow = 0.40f;      // patch -> window when fewer than this share of the samples are far ...
+constexpr float kFarToPatch = 0.48f;       // ... window -> patch above this one (crossover measured at ~0.45: sigma 3.6 px)
 struct FwdAdapt {
     unsigned *dev_cnt = nullptr;           // device words: {far, total, kind, -} x launch parity, [8] = publications so far
     unsigned *pub_host = nullptr;          // mapped pinned memory {sequence, far, total, kind}
@@ -452,8 +452,11 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
         bool use_window = false;
         if (int rc = fwd_adapt_next(st, window_ok, fs, use_window)) return rc;
         if (use_window) {
-            auto kern = &msda_rw_d32<IO, 512, 16, 16, -1, 4, 4, false, 0, 40>;
-            constexpr size_t wlds = rw_lds_bytes<512, 16, 16, -1, 4, 4>();
+            // 16 x 16 regions, level 0 through global loads, windows of the three coarse levels with a margin of SIX pixels: 159 KB
+            // of LDS, one 512-thread workgroup per CU either way, so the widest margin that fits is the best one (margin 4 / 5 / 6 at
+            // sigma 2 px: 239 / 231 / 219-229 us, at 3 px: 290 / 265 / 252 us; only at 1 px margin 4 is ahead, 205 against 214 us)
+            auto kern = &msda_rw_d32<IO, 512, 16, 16, -1, 6, 4, false, 0, 40>;
+            constexpr size_t wlds = rw_lds_bytes<512, 16, 16, -1, 6, 4>();
             static_assert(wlds <= 160 * 1024, "region-window configuration does not fit the LDS");
             if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
             // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,

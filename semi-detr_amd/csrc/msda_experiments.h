@@ -46,6 +46,12 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 4: if constexpr (!GATHER) return RWT(256, 8, 8, -1, 4, 0, 40); else break;
         case 5: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 0, 40); else break;      // level 0 through global loads
         case 6: if constexpr (!GATHER) return RWT(512, 8, 16, -1, 5, 0, 40); else break;
+        case 15: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 5, 0, 40); else break;      // the product's shape with margin 5 (134 KB of LDS)
+        case 16: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 40); else break;      // margin 6: 159 KB of LDS
+        case 17: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 5, 1, 40); else break;      // ... instrumented
+        case 12: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 1, 40); else break;      // the PRODUCT configuration (702), instrumented
+        case 13: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 2, 40); else break;      // ... windows not staged (timing aid)
+        case 14: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 3, 40); else break;      // ... LDS loop skipped (timing aid)
         case 7: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 1, 40); else return RWT(512, 8, 16, 4, 5, 1, 40);
         case 8: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 2, 40); else return RWT(512, 8, 16, 4, 5, 2, 40);
         case 9: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 3, 40); else return RWT(512, 8, 16, 4, 5, 3, 40);
@@ -102,7 +108,7 @@ int exp_launch_fast_forward(hipStream_t st, const float *value, const int64_t *s
         g_last_kernels = "msda_fwd_d32_ws";
         return semidetr::launch_status("msda_fwd_d32_ws");
     }
-    if (g_fwd_variant >= 700 && g_fwd_variant <= 709) {
+    if (g_fwd_variant >= 700 && g_fwd_variant <= 719) {
         SEMIDETR_REQUIRE(pixels && P == kPT && (L == 4 || L == 5), SEMIDETR_E_BADARG,
                          "msda_forward: the region-window kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, 4 or 5 levels");
         g_last_kernels = "msda_rw_d32";

@@ -135,8 +135,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     const int m = (b % M + (b / M) / kRwHeadRun) % M;
     const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
     // how far the samples reach, for the dispatcher's choice between this kernel and the patch kernel (FwdStats, msda_fast.h):
-    // one workgroup in 32 counts, the launch's first thread publishes the previous launch's pair
-    const bool sampled = !GATHER && fs.cur != nullptr && (b & 31) == 1;
+    // one workgroup in 128 counts (its first round: 64 queries x 12 samples; ~20 workgroups of a bs-4 launch), the launch's first
+    // workgroup publishes the previous launch's pair
+    const bool sampled = !GATHER && fs.cur != nullptr && (b & 127) == 1;
     unsigned st_far = 0, st_total = 0;
 
     if (GATHER && zero) {      // side job: clear grad_value, which the scatter launch that FOLLOWS accumulates into

@@ -10,8 +10,9 @@ dev = torch.device("cuda:0")
 v, sh, st, loc, attn, gout, Sx, Lx, lq = bench._msda_case(dev, bench.LEVELS, 4, 0, True)
 gout = torch.rand_like(gout)
 names = ["setup", "stage_issue", "boundary_wait", "stage_store", "store_wait", "geometry", "next_loads", "compute", "outside", "results"]
-for which in ("fwd", "bwd"):
-    sda._lib.set_variant(707, 7007)
+fv = int(sys.argv[1]) if len(sys.argv) > 1 else 707
+for which in (("fwd", "bwd") if fv == 707 else ("fwd",)):
+    sda._lib.set_variant(fv, 7007 if fv == 707 else 0)
     buf = (ctypes.c_ulonglong * 16)()
     run = (lambda: MSDA.ms_deform_attn_forward(v, sh, st, loc, attn, 64)) if which == "fwd" else \
           (lambda: MSDA.ms_deform_attn_backward(v, sh, st, loc, attn, gout, 64))
