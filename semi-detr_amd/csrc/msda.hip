@@ -41,6 +41,11 @@
 namespace {
 
 constexpr int kMaxLevels = 32;
+#ifndef SEMIDETR_RW_TUNE
+#define SEMIDETR_RW_TUNE 20      // msda_rw_d32: compute-loop samples between scheduling barriers x 10 (+ pre-issued out-of-window samples).
+                                 // 20, not round 3's 40: the kernel lives at the 256-VGPR limit, and with four samples' LDS reads in
+                                 // flight the compiler spilled (reference contract 202 -> 193 us, fused prologue 242 -> 207 us; 10: 199 / 214)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // sample geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 corner validity)
@@ -455,7 +460,7 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             // 16 x 16 regions, level 0 through global loads, windows of the three coarse levels with a margin of SIX pixels: 159 KB
             // of LDS, one 512-thread workgroup per CU either way, so the widest margin that fits is the best one (margin 4 / 5 / 6 at
             // sigma 2 px: 239 / 231 / 219-229 us, at 3 px: 290 / 265 / 252 us; only at 1 px margin 4 is ahead, 205 against 214 us)
-            auto kern = &msda_rw_d32<IO, 512, 16, 16, -1, 6, 4, false, 0, 40>;
+            auto kern = &msda_rw_d32<IO, 512, 16, 16, -1, 6, 4, false, 0, SEMIDETR_RW_TUNE>;
             constexpr size_t wlds = rw_lds_bytes<512, 16, 16, -1, 6, 4>();
             static_assert(wlds <= 160 * 1024, "region-window configuration does not fit the LDS");
             if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
