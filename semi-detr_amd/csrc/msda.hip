@@ -369,6 +369,7 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 //      next gets here, it never waits -- moves between the kernels with hysteresis.  Per device; a mutex serialises the few
 //      host words.  semidetr_msda_set_forward_policy pins the choice (tests, A/B timing).
 constexpr float kFarToWindow = 0.40f;      // patch -> window when fewer than this share of the samples are far ...
+constexpr float kFarToWindowOneImage = 0.28f;      // a launch of ONE image takes the window kernel only below this share (sigma ~2.8 px)
 constexpr float kFarToPatch = 0.48f;       // ... window -> patch above this one (crossover measured at ~0.45: sigma 3.6 px)
 struct FwdAdapt {
     unsigned *dev_cnt = nullptr;           // device words: {far, total, kind, -} x launch parity, [8] = publications so far
@@ -385,7 +386,7 @@ FwdAdapt g_adapt[kMaxDevices];
 std::atomic<int> g_fwd_policy{0};          // 0 adaptive, 1 always the patch kernel, 2 the window kernel whenever it applies
 
 // the launch's FwdStats and the kernel to use; called with the stream the launch goes to
-int fwd_adapt_next(hipStream_t st, bool allow_window, FwdStats &fs, bool &use_window)
+int fwd_adapt_next(hipStream_t st, bool allow_window, int batch, FwdStats &fs, bool &use_window)
 {
     fs = FwdStats{nullptr, nullptr, nullptr, nullptr};
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
@@ -430,7 +431,7 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, FwdStats &fs, bool &use_wi
             fs = FwdStats{a.dev_cnt + 4 * par, a.dev_cnt + 4 * (1 - par), a.pub_dev, a.dev_cnt + 8};
         }
     }
-    use_window = a.mode == 1;
+    use_window = a.mode == 1 && (batch >= 2 || (a.last_frac >= 0.f && a.last_frac < kFarToWindowOneImage));
     return SEMIDETR_OK;
 }
 
@@ -449,13 +450,13 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
     hipLaunchKernelGGL((msda_fwd_d32<SP, 4, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        (LDS), st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
     if (pixels) {
-        // encoder self-attention.  The region-window kernel is built for num_point == 4 and four levels, takes no padding
-        // mask (its windows are staged from `value` as it is) and needs >= 2 images' worth of regions to fill the chip
-        // (one 512-thread workgroup per CU; at bs 1 it only pays below sigma ~1.7 px)
-        const bool window_ok = P == kPT && L == 4 && !io.has_mask() && N >= 2;
+        // encoder self-attention.  The region-window kernel is built for num_point == 4 and four levels and takes no padding
+        // mask (its windows are staged from `value` as it is).  One image alone fills the chip less well (616 regions x heads for
+        // 256 CUs): there it is ahead of the patch kernel up to sigma ~3 px instead of ~3.6 px (61 vs 67 us at 2 px)
+        const bool window_ok = P == kPT && L == 4 && !io.has_mask();
         FwdStats fs;
         bool use_window = false;
-        if (int rc = fwd_adapt_next(st, window_ok, fs, use_window)) return rc;
+        if (int rc = fwd_adapt_next(st, window_ok, N, fs, use_window)) return rc;
         if (use_window) {
             // 16 x 16 regions, level 0 through global loads, windows of the three coarse levels with a margin of SIX pixels: 159 KB
             // of LDS, one 512-thread workgroup per CU either way, so the widest margin that fits is the best one (margin 4 / 5 / 6 at

@@ -49,6 +49,8 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 15: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 5, 0, 40); else break;      // the product's shape with margin 5 (134 KB of LDS)
         case 16: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 40); else break;      // margin 6: 159 KB of LDS
         case 17: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 5, 1, 40); else break;      // ... instrumented
+        case 18: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 20); else break;      // the PRODUCT configuration since round 4
+        case 19: if constexpr (!GATHER) return RWT(256, 16, 16, -1, 6, 0, 20); else break;      // ... with 256-thread workgroups
         case 12: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 1, 40); else break;      // the PRODUCT configuration (702), instrumented
         case 13: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 2, 40); else break;      // ... windows not staged (timing aid)
         case 14: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 3, 40); else break;      // ... LDS loop skipped (timing aid)

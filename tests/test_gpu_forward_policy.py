@@ -4,7 +4,7 @@
   * parity: patch kernel (policy "patch") and region-window kernel (policy "window") against the CPU oracle on the same
     inputs -- small pyramids incl. ragged edges / far samples / samples outside the map, the full-size bs-4 encoder shape
     for the reference contract AND the fused prologue, and bitwise-equal results where the window kernel does not apply
-    (padding mask, five levels, one image);
+    (padding mask, five levels);
   * the adaptive policy: close samples move the dispatcher to the window kernel, far ones move it back, and what the
     library reports as launched is what the policy state says.
 """
@@ -90,11 +90,16 @@ def test_window_forward_full_size_vs_oracle(io):
 
 
 def test_window_policy_keeps_the_patch_kernel_where_the_window_kernel_does_not_apply():
-    """One image, five levels, a padding mask: policy "window" must fall back to the patch kernel (and give its results)."""
+    """Five levels, three points, a padding mask: policy "window" must fall back to the patch kernel (and give its results)."""
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd as sda
     sda._lib.set_forward_policy("window")
-    for shapes, N in (([(20, 27), (10, 14), (5, 7), (3, 4)], 1), ([(20, 27), (10, 14), (5, 7), (3, 4), (2, 2)], 2)):
+    value, shp, loc, attn = _case([(20, 27), (10, 14), (5, 7), (3, 4)], 1, "near", 8)      # ONE image does take the window kernel
+    tsh = _t(shp)
+    out = MSDA.ms_deform_attn_forward(_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)
+    assert _last() == "msda_rw_d32", _last()
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.msda_forward(value, shp, loc, attn), rtol=0, atol=2e-6)
+    for shapes, N in (([(20, 27), (10, 14), (5, 7), (3, 4), (2, 2)], 2),):
         value, shp, loc, attn = _case(shapes, N, "near", 9)
         tsh = _t(shp)
         out = MSDA.ms_deform_attn_forward(_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)
