@@ -41,6 +41,18 @@
 namespace {
 
 constexpr int kMaxLevels = 32;
+// A/B knobs of tools/r04_ab_multi.sh (same-box comparison of several builds inside the bench step).  Round 4, rotated inputs:
+// encoder gather with 8 instead of 16 corner loads in flight at five waves per SIMD: backward 701 -> 695 us at bs 4 (with
+// replayed inputs round 2 had measured it level); region scatter with 176 queries per pass at six waves per SIMD (three
+// workgroups per CU, 13 VGPRs spilled): 702 vs 701 us at bs 4, 205 vs 196 us at bs 1 -- not adopted.
+#ifndef SEMIDETR_GATHER_WPE      // encoder gather: waves per SIMD the register budget is set for, corner loads in flight / 4
+#define SEMIDETR_GATHER_WPE 5
+#define SEMIDETR_GATHER_KB 2
+#endif
+#ifndef SEMIDETR_SCATTER_Q       // region scatter: queries per pass (LDS) and waves per SIMD
+#define SEMIDETR_SCATTER_Q 208
+#define SEMIDETR_SCATTER_WPE 4
+#endif
 #ifndef SEMIDETR_RW_TUNE
 #define SEMIDETR_RW_TUNE 20      // msda_rw_d32: compute-loop samples between scheduling barriers x 10 (+ pre-issued out-of-window samples).
                                  // 20, not round 3's 40: the kernel lives at the 256-VGPR limit, and with four samples' LDS reads in
@@ -523,7 +535,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         SEMIDETR_REQUIRE((int64_t)N * std::max(gbound, gt) * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
         float4 *zero = fill_in_gather ? reinterpret_cast<float4 *>(grad_value) : nullptr;
         if (L * P == 16)             // DINO: sample loop unrolled, results in registers
-            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
+            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, SEMIDETR_GATHER_WPE, SEMIDETR_GATHER_KB>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound, zero, (int64_t)(fill / 16));
         else if (L * P == 20)        // five levels (COCO-Full recipe)
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 20, 408>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
@@ -532,8 +544,8 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
         if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
-        auto kern = &msda_bwd_scatter_d32_reg<IO, 512, 208, 8, 16, 24, 32, 0, 4, 8>;
-        const size_t rlds = reg_lds_bytes<512, 208, 24, 32>();
+        auto kern = &msda_bwd_scatter_d32_reg<IO, 512, SEMIDETR_SCATTER_Q, 8, 16, 24, 32, 0, SEMIDETR_SCATTER_WPE, 8>;
+        const size_t rlds = reg_lds_bytes<512, SEMIDETR_SCATTER_Q, 24, 32>();
         if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
         const int rbound = (S + 127) / 128 * 5 / 4 + 4 * L;
         const int64_t rgrid = (int64_t)N * rbound * M;
