@@ -380,9 +380,9 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 //      handed to the host by the first thread of launch k + 1 through mapped pinned memory, and the dispatcher -- whenever it
 //      next gets here, it never waits -- moves between the kernels with hysteresis.  Per device; a mutex serialises the few
 //      host words.  semidetr_msda_set_forward_policy pins the choice (tests, A/B timing).
-constexpr float kFarToWindow = 0.40f;      // patch -> window when fewer than this share of the samples are far ...
+constexpr float kFarToWindow = 0.46f;      // patch -> window when fewer than this share of the samples are far ...
 constexpr float kFarToWindowOneImage = 0.28f;      // a launch of ONE image takes the window kernel only below this share (sigma ~2.8 px)
-constexpr float kFarToPatch = 0.48f;       // ... window -> patch above this one (crossover measured at ~0.45: sigma 3.6 px)
+constexpr float kFarToPatch = 0.55f;       // ... window -> patch above this one (the kernels are level at ~0.53: sigma 4 px)
 struct FwdAdapt {
     unsigned *dev_cnt = nullptr;           // device words: {far, total, kind, -} x launch parity, [8] = publications so far
     unsigned *pub_host = nullptr;          // mapped pinned memory {sequence, far, total, kind}

@@ -149,9 +149,9 @@ def test_adaptive_policy_follows_the_sample_spread():
     k_close = run(1.0, 6)
     st1 = sda._lib.forward_policy_state()
     assert st1["updates"] > st0["updates"], (st0, st1)
-    assert st1["mode"] == 1 and 0.0 <= st1["far_fraction"] < 0.40, st1
+    assert st1["mode"] == 1 and 0.0 <= st1["far_fraction"] < 0.46, st1
     assert k_close[-1] == "msda_rw_d32", k_close
     k_far = run(6.0, 6)
     st2 = sda._lib.forward_policy_state()
-    assert st2["mode"] == 0 and st2["far_fraction"] > 0.48, st2
+    assert st2["mode"] == 0 and st2["far_fraction"] > 0.55, st2
     assert k_far[0] == "msda_rw_d32" and k_far[-1] == "msda_fwd_d32<1, 4, 408", k_far
