@@ -40,9 +40,9 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
     if constexpr (KL == 4) {
         switch (cfg) {
         case 0: return RWT(512, 8, 16, 4, 5, 0, 40);
-        case 1: if constexpr (!GATHER) return RWT(256, 16, 16, -1, 4, 0, 40); else break;
-        case 2: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 0, 40); else break;
-        case 3: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 3, 0, 40); else break;
+        case 1: if constexpr (!GATHER) return RWT(256, 16, 16, -1, 4, 0, 40); else return RWT(512, 8, 16, 4, 5, 0, 20);      // gather: a sample per scheduling barrier
+        case 2: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 0, 40); else return RWT(512, 8, 16, 4, 4, 0, 20);
+        case 3: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 3, 0, 40); else return RWT(512, 8, 16, 4, 5, 0, 60);
         case 4: if constexpr (!GATHER) return RWT(256, 8, 8, -1, 4, 0, 40); else break;
         case 5: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 0, 40); else break;      // level 0 through global loads
         case 6: if constexpr (!GATHER) return RWT(512, 8, 16, -1, 5, 0, 40); else break;

@@ -69,6 +69,11 @@ def test_host_side_argument_errors_need_no_gpu():
     assert rc == -1 and b"null pointer" in lib.semidetr_last_error()
     rc = lib.semidetr_ema_flat_f32(None, None, None, -5, 0.5)
     assert rc == -1
+    # round 4: the forward-kernel policy is validated on the host (0 adaptive, 1 patch, 2 window)
+    assert lib.semidetr_msda_set_forward_policy(3) == -1 and b"0 adaptive" in lib.semidetr_last_error()
+    assert lib.semidetr_msda_set_forward_policy(-1) == -1
+    for ok in (2, 1, 0):
+        assert lib.semidetr_msda_set_forward_policy(ok) == 0
     assert lib.semidetr_lsap_workspace_bytes(35, 900, 100) == 0          # fits LDS
     assert lib.semidetr_lsap_workspace_bytes(2, 22223, 10) > 0           # does not
     with pytest.raises(RuntimeError, match="code -1"):
