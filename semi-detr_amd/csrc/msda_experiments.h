@@ -60,6 +60,10 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         default: break;
         }
     }
+    if constexpr (KL == 5 && !GATHER) {      // round 4: the product's shape for five levels (level 0 global, 16 x 16 regions)
+        if (cfg == 15) return RWT(512, 16, 16, -1, 4, 0, 20);
+        if (cfg == 18) return RWT(512, 16, 16, -1, 5, 0, 20);
+    }
     if constexpr (KL == 4) return RWT(512, 8, 16, 4, 5, 0, 40);
     else return RWT(512, 8, 16, 4, 4, 0, 40);      // five levels: the margin-5 windows do not fit 160 KB
 #undef RWT
@@ -116,7 +120,7 @@ int exp_launch_fast_forward(hipStream_t st, const float *value, const int64_t *s
         g_last_kernels = "msda_rw_d32";
         if (L == 4)
             return launch_rw_cfg<IO, 4, false>(g_fwd_variant - 700, st, nullptr, value, spatial_shapes, level_start, io, N, S, M, out, nullptr, 0);
-        return launch_rw_cfg<IO, 5, false>(0, st, nullptr, value, spatial_shapes, level_start, io, N, S, M, out, nullptr, 0);
+        return launch_rw_cfg<IO, 5, false>(g_fwd_variant - 700, st, nullptr, value, spatial_shapes, level_start, io, N, S, M, out, nullptr, 0);
     }
     if (g_fwd_variant >= 500 && g_fwd_variant <= 505) {
         SEMIDETR_REQUIRE(pixels, SEMIDETR_E_BADARG, "msda_forward: the resident-level kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS");

@@ -431,9 +431,9 @@ __device__ __forceinline__ int patch_query(const Patch &p, int r)      // r-th q
 
 // ---------------------------------------------------------------------------------------------
 // How far the samples of an encoder self-attention launch reach -- the statistic the dispatcher picks the forward kernel by
-// (msda.hip: launch_fast_forward).  The region-window kernel (msda_rw.h) serves the corners from LDS windows placed +- 4 px
-// around a region: 8-14 % faster than the patch kernel while the learned offsets stay inside, slower once a fifth of the
-// samples leave (profiles/r04_region_window_dispatch.txt).  Both kernels therefore count, in a few sampled workgroups,
+// (msda.hip: launch_fast_forward).  The region-window kernel (msda_rw.h) serves the coarse levels' corners from LDS windows placed
+// +- 6 px around a region: 4-18 % faster than the patch kernel up to sigma ~3.5 px, level with it at 4 px, slower beyond
+// (profiles/r04_region_window_dispatch.txt).  Both kernels therefore count, in a few sampled workgroups,
 //     far   = samples on levels >= 1 more than kFarPx pixels (of the sampled level) from their query's own pixel centre
 //     total = samples on levels >= 1
 // into a device-side counter pair; the NEXT launch's first thread hands the finished pair to the host through mapped pinned
