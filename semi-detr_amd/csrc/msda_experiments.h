@@ -616,6 +616,13 @@ int exp_launch_fast_backward(hipStream_t st, const float *grad_out, const float 
             else if (g_bwd_variant == 699) LAUNCH_REGW(512, 176, 8, 16, 24, 32, 4);   // same LDS, register budget of two
             else if (g_bwd_variant == 6981) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 4);    // walk unrolled by 4
             else if (g_bwd_variant == 6982) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 16);   // ... by 16
+            else if (g_bwd_variant == 6985) {                                              // timing aid: no row atomics
+                auto kern = &msda_bwd_scatter_d32_reg_noatomics<IO>;
+                const size_t rlds = reg_lds_bytes<512, 208, 24, 32>();
+                if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
+                hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L,
+                                   rbound, grad_value);
+            }
             else if (g_bwd_variant == 6983) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 108);  // b128 entry reads, next batch prefetched
             else if (g_bwd_variant == 6984) LAUNCH_REGU(512, 208, 8, 16, 24, 32, 4, 104);  // same, batches of 4
             else if (small) LAUNCH_REG(512, 208, 8, 16, 24, 32);

@@ -566,6 +566,16 @@ __global__ __launch_bounds__(NT, WPE) void msda_bwd_scatter_d32_reg(
 }
 
 #if SEMIDETR_EXPERIMENTS
+// timing aid (backward variant 6985, results wrong): the region scatter WITHOUT its row atomics -- what the compute side alone costs
+template <typename IO>
+__global__ __launch_bounds__(512, 4) void msda_bwd_scatter_d32_reg_noatomics(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    reg_scatter_body<IO, 512, 208, 8, 16, 24, 32, 0, 8, 0, 2>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, regions_bound, gvalue);
+}
+
 // EXPERIMENT (round 4, backward variants 6900-6911; measured and rejected): the WHOLE encoder backward in one
 // kernel -- the region scatter above plus the two small gradients (reg_scatter_body<..., FUSE>).  Once the (sample, corner)
 // pairs of a level are bucketed, their dot products <grad_out[query], value[corner]> take one pass with a lane per entry
