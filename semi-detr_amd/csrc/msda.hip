@@ -53,10 +53,16 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_SCATTER_Q 208
 #define SEMIDETR_SCATTER_WPE 4
 #endif
+#ifndef SEMIDETR_RW_NT
+#define SEMIDETR_RW_NT 768       // msda_rw_d32: threads per workgroup.  Its windows take most of the LDS, so a CU holds ONE workgroup and
+                                 // the workgroup's size is the CU's occupancy: 12 instead of 8 waves 192.9 -> 176.7 us inside the step
+                                 // (1024 threads: only with margin 5 and 25 spilled registers so far, 262 us)
+#endif
 #ifndef SEMIDETR_RW_TUNE
-#define SEMIDETR_RW_TUNE 20      // msda_rw_d32: compute-loop samples between scheduling barriers x 10 (+ pre-issued out-of-window samples).
-                                 // 20, not round 3's 40: the kernel lives at the 256-VGPR limit, and with four samples' LDS reads in
-                                 // flight the compiler spilled (reference contract 202 -> 193 us, fused prologue 242 -> 207 us; 10: 199 / 214)
+#define SEMIDETR_RW_TUNE 320     // msda_rw_d32: 10 x compute-loop samples between scheduling barriers (two: with four samples' LDS reads
+                                 // in flight round 4's first version spilled; one: 2 us slower) + 100: one level-0 sample's corner loads in
+                                 // flight instead of two (-33 VGPRs) + 200: level constants re-selected where they are used and staging
+                                 // coordinates rebuilt per region instead of living in registers (256 -> 160 VGPRs: what lets 768 threads run)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -470,18 +476,19 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
         bool use_window = false;
         if (int rc = fwd_adapt_next(st, window_ok, N, fs, use_window)) return rc;
         if (use_window) {
-            // 16 x 16 regions, level 0 through global loads, windows of the three coarse levels with a margin of SIX pixels: 159 KB
-            // of LDS, one 512-thread workgroup per CU either way, so the widest margin that fits is the best one (margin 4 / 5 / 6 at
-            // sigma 2 px: 239 / 231 / 219-229 us, at 3 px: 290 / 265 / 252 us; only at 1 px margin 4 is ahead, 205 against 214 us)
-            auto kern = &msda_rw_d32<IO, 512, 16, 16, -1, 6, 4, false, 0, SEMIDETR_RW_TUNE>;
-            constexpr size_t wlds = rw_lds_bytes<512, 16, 16, -1, 6, 4>();
+            // 16 x 16 regions, level 0 through global loads, windows of the three coarse levels with a margin of SIX pixels: 123 KB of
+            // windows + 34.5 KB of octet records = one workgroup per CU either way, so the widest margin that fits is the best one
+            // (margin 4 / 5 / 6 at sigma 2 px: 239 / 231 / 219-229 us, at 3 px: 290 / 265 / 252 us) and the workgroup is as large as its
+            // registers allow (SEMIDETR_RW_NT above)
+            auto kern = &msda_rw_d32<IO, SEMIDETR_RW_NT, 16, 16, -1, 6, 4, false, 0, SEMIDETR_RW_TUNE>;
+            constexpr size_t wlds = rw_lds_bytes<SEMIDETR_RW_NT, 16, 16, -1, 6, 4>();
             static_assert(wlds <= 160 * 1024, "region-window configuration does not fit the LDS");
             if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
             // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
             // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
             const int wbound = ((S * 3 / 4 + 255) / 256) * 9 / 8 + 2 * L;
             SEMIDETR_REQUIRE((int64_t)N * wbound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
-            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(512), wlds, st, (const float *)nullptr, value,
+            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(SEMIDETR_RW_NT), wlds, st, (const float *)nullptr, value,
                                spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs);
             g_last_kernels = "msda_rw_d32";
             return semidetr::launch_status("msda_rw_d32<forward>");

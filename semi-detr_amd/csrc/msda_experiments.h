@@ -49,8 +49,22 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 15: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 5, 0, 40); else break;      // the product's shape with margin 5 (134 KB of LDS)
         case 16: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 40); else break;      // margin 6: 159 KB of LDS
         case 17: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 5, 1, 40); else break;      // ... instrumented
-        case 18: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 20); else break;      // the PRODUCT configuration since round 4
+        case 18: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 20); else break;      // round 4's first product configuration (512 threads)
         case 19: if constexpr (!GATHER) return RWT(256, 16, 16, -1, 6, 0, 20); else break;      // ... with 256-thread workgroups
+        // round 4, second look: does the kernel want more waves?  1024-thread workgroups = 16 waves per CU (128 VGPRs); their octet
+        // records take 66 KB, so the margin drops to 4 -- compared at equal margin (730 = 512 threads)
+        // TUNE + 100: one level-0 sample in flight instead of two; + 200: lean registers (level constants re-selected where they
+        // are used, staging coordinates rebuilt per region) -- 160 instead of 256 VGPRs, which is what lets a 768-thread workgroup run
+        case 30: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 0, 20); else break;
+        case 31: if constexpr (!GATHER) return RWT(1024, 16, 16, -1, 5, 0, 320); else break;     // 25 VGPRs spilled
+        case 32: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 220); else break;      // the product shape, lean
+        case 33: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 240); else break;      // ... four samples between barriers again
+        case 34: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 320); else break;      // the PRODUCT configuration: 12 waves per CU, margin 6
+        case 35: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 310); else break;
+        case 36: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 5, 0, 320); else break;
+        case 37: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 320); else break;
+        case 38: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 340); else break;
+        case 39: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 120); else break;
         case 12: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 1, 40); else break;      // the PRODUCT configuration (702), instrumented
         case 13: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 2, 40); else break;      // ... windows not staged (timing aid)
         case 14: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 3, 40); else break;      // ... LDS loop skipped (timing aid)
@@ -114,7 +128,7 @@ int exp_launch_fast_forward(hipStream_t st, const float *value, const int64_t *s
         g_last_kernels = "msda_fwd_d32_ws";
         return semidetr::launch_status("msda_fwd_d32_ws");
     }
-    if (g_fwd_variant >= 700 && g_fwd_variant <= 719) {
+    if ((g_fwd_variant >= 700 && g_fwd_variant <= 719) || (g_fwd_variant >= 730 && g_fwd_variant <= 749)) {
         SEMIDETR_REQUIRE(pixels && P == kPT && (L == 4 || L == 5), SEMIDETR_E_BADARG,
                          "msda_forward: the region-window kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, 4 or 5 levels");
         g_last_kernels = "msda_rw_d32";

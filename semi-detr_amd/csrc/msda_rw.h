@@ -71,9 +71,11 @@ struct RwWin {
 };
 
 template <int KL, bool FG = false>
-constexpr int rw_oct_bytes()      // per octet: KLP x {float4 record} | KLP x {two 16-bit window offsets} | two 32-byte slots (+ bank spread)
+constexpr int rw_oct_bytes()      // per octet: {float4 record} and {two 16-bit window offsets} per windowed sample | two 32-byte slots (+ bank spread)
 {
-    constexpr int raw = KL * kPT * 20 + 64 + (FG ? kPT * 32 : 0);
+    // level 0 without a window (FG): its samples have no window record; their {corner offsets, weights} records (32 bytes each) are
+    // dead by the time the out-of-window loop needs its two slots, so the slots lie on top of them
+    constexpr int raw = FG ? (KL - 1) * kPT * 20 + kPT * 32 : KL * kPT * 20 + 64;
     return raw + (raw % 128 == 0 ? 16 : 0);      // octet pitch: A, B, C, D on distinct banks
 }
 
@@ -109,7 +111,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     constexpr bool FG = Wn::fine_global;                  // level 0 through global loads (forward only)
     static_assert(!FG || !GATHER, "the gather keeps a window for every level");
     constexpr int kOctBytes = rw_oct_bytes<KL, FG>();
-    constexpr int kOffAt = KLP * 16, kSlotAt = KLP * 20, kFineAt = KLP * 20 + 64;
+    constexpr int kRec0 = FG ? P : 0;                     // first sample with a window record
+    constexpr int kOffAt = (KLP - kRec0) * 16, kFineAt = (KLP - kRec0) * 20, kSlotAt = kFineAt;
+    static_assert(!FG || TUNE % 10 == 0, "without a level-0 window the slots of pre-issued out-of-window samples would overwrite live records");
     static_assert(Wn::total * 128 <= (1 << 20), "window offsets are kept in 16 bits, in units of 16 bytes");
     constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
     static_assert(P == 4 && KLP <= 32, "lane j of an octet owns samples j, j + 8, ...");
@@ -187,6 +191,28 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         my_row0[p] = __shfl(r_row0, l, 64);
     }
 
+    // TUNE >= 200: no per-lane copies of the level constants (22 VGPRs that live through the whole kernel); a pass's two levels
+    // are compile-time, so each constant is ONE select between two wave-uniform values, redone where it is needed (the lane
+    // predicate goes through an empty asm so that the selects are not hoisted back out of the round loop)
+    constexpr bool kLean = ((TUNE / 100) & 2) != 0;
+    static_assert(!kLean || P == 4, "a pass covers two levels: lanes 0-3 / 4-7");
+    struct LvlC { int l, H, W, st, wh1, ww1, ww, row0; };
+    auto lvlc = [&](int p) -> LvlC {
+        if constexpr (!kLean) {
+            return LvlC{myl[p], myH[p], myW[p], myst[p], my_wh1[p], my_ww1[p], my_ww[p], my_row0[p]};
+        } else {
+            int jj = j8;
+            asm volatile("" : "+v"(jj));
+            const bool hi = jj >= P;
+            const int la = min(2 * p, KL - 1), lb = min(2 * p + 1, KL - 1);
+            // (readfirstlane keeps "select of two array loads" from becoming "load at a selected index" = scratch)
+            auto u = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+            return LvlC{hi ? lb : la, hi ? u(Hs[lb]) : u(Hs[la]), hi ? u(Ws[lb]) : u(Ws[la]), hi ? u(sts[lb]) : u(sts[la]),
+                        hi ? Wn::wh(lb) - 1 : Wn::wh(la) - 1, hi ? Wn::ww(lb) - 1 : Wn::ww(la) - 1,
+                        hi ? Wn::ww(lb) : Wn::ww(la), hi ? Wn::row0(lb) : Wn::row0(la)};
+        }
+    };
+
     char *const orec = recs + oc * kOctBytes;             // this octet's records
     const char *const wbase = lds + j8 * 16;
 
@@ -221,9 +247,19 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         int my_wy0[NPASS], my_wx0[NPASS];
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            my_wy0[p] = __shfl(r_wy0, myl[p], 64);
-            my_wx0[p] = __shfl(r_wx0, myl[p], 64);
+            my_wy0[p] = kLean ? 0 : __shfl(r_wy0, myl[p], 64);
+            my_wx0[p] = kLean ? 0 : __shfl(r_wx0, myl[p], 64);
         }
+        auto win_origin = [&](int p, int l, int &oy, int &ox) {      // window origin of level l = lvlc(p).l
+            if constexpr (!kLean) {
+                oy = my_wy0[p];
+                ox = my_wx0[p];
+            } else {
+                const int la = min(2 * p, KL - 1), lb = min(2 * p + 1, KL - 1);
+                oy = l == lb ? __builtin_amdgcn_readfirstlane(wy0[lb]) : __builtin_amdgcn_readfirstlane(wy0[la]);
+                ox = l == lb ? __builtin_amdgcn_readfirstlane(wx0[lb]) : __builtin_amdgcn_readfirstlane(wx0[la]);
+            }
+        };
 
         // ---- rounds: G queries at a time, 8 lanes each
         const int nrounds = (nq_total + G - 1) / G;
@@ -250,7 +286,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 rx[p] = ry[p] = ra[p] = 0.f;
                 if (qq >= 0 && k < KLP) {
                     const int64_t nq = (int64_t)n * Lq + qq, row = nq * M + m;
-                    io.load_xy(row, nq, KLP, k, myl[p], P, myH[p], myW[p], rx[p], ry[p]);
+                    const LvlC c = lvlc(p);
+                    io.load_xy(row, nq, KLP, k, c.l, P, c.H, c.W, rx[p], ry[p]);
                     ra[p] = io.load_w(row, KLP, k);
                 }
             }
@@ -265,12 +302,14 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             constexpr int RPS = NT / 8;                                   // window rows covered per step (8 lanes per row)
             constexpr int kMaxSteps = (Wn::zrow + RPS - 1) / RPS + KL;
             float4 sv[kMaxSteps];
+            int ocs = oc;      // lean builds: the per-thread window coordinates below are rebuilt per region, not kept in registers
+            if (kLean) asm volatile("" : "+v"(ocs));
             if (DBG != 2) {
                 int nst = 0;
 #pragma unroll
                 for (int l = 0; l < KL; ++l) {
                     const int ww_ = Wn::ww(l), rows_ = Wn::rows(l);
-                    int r = oc, wy = oc / ww_, wx = oc - wy * ww_;           // this thread's row inside level l's window
+                    int r = ocs, wy = ocs / ww_, wx = ocs - wy * ww_;        // this thread's row inside level l's window
 #pragma unroll
                     for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
                         const int py = wy0[l] + wy, px = wx0[l] + wx;
@@ -292,7 +331,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
 #pragma unroll
                 for (int l = 0; l < KL; ++l) {
                     const int rows_ = Wn::rows(l);
-                    int r = oc;
+                    int r = ocs;
 #pragma unroll
                     for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
                         if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8 * 16) = sv[ist];
@@ -349,27 +388,32 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 const int qy = (int)(((float)pix + 0.5f) / (float)Wq), qx = pix - qy * Wq;      // pix < 2^23: exact
                 const float cx = ((float)qx + 0.5f) / (float)Wq, cy = ((float)qy + 0.5f) / (float)Hq;
 #pragma unroll
-                for (int p = 0; p < NPASS; ++p)
-                    if (j8 + 8 * p < KLP && myl[p] >= 1) {
+                for (int p = 0; p < NPASS; ++p) {
+                    const LvlC c = lvlc(p);
+                    if (j8 + 8 * p < KLP && c.l >= 1) {
                         st_total += 1u;
-                        st_far += (fabsf((sx[p] - cx) * (float)myW[p]) > kFarPx || fabsf((sy[p] - cy) * (float)myH[p]) > kFarPx) ? 1u : 0u;
+                        st_far += (fabsf((sx[p] - cx) * (float)c.W) > kFarPx || fabsf((sy[p] - cy) * (float)c.H) > kFarPx) ? 1u : 0u;
                     }
+                }
             }
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 const int k = j8 + 8 * p;
-                const float Hf = (float)myH[p], Wf = (float)myW[p];
+                const LvlC c = lvlc(p);
+                int c_wy0, c_wx0;
+                win_origin(p, c.l, c_wy0, c_wx0);
+                const float Hf = (float)c.H, Wf = (float)c.W;
                 const float h = sub_rn(mul_rn(sy[p], Hf), 0.5f), w = sub_rn(mul_rn(sx[p], Wf), 0.5f);
                 const bool inside = q >= 0 && k < KLP && h > -1.f && w > -1.f && h < Hf && w < Wf;
                 const float h0f = floorf(h), w0f = floorf(w);
                 const float lh = sub_rn(h, h0f), lw = sub_rn(w, w0f);
-                const int wy = (int)h0f - my_wy0[p], wx = (int)w0f - my_wx0[p];
-                const bool inwin = inside && (unsigned)wy < (unsigned)my_wh1[p] && (unsigned)wx < (unsigned)my_ww1[p];
-                const bool fine = FG && myl[p] == 0;             // level 0 without a window: global corner offsets instead
+                const int wy = (int)h0f - c_wy0, wx = (int)w0f - c_wx0;
+                const bool inwin = inside && (unsigned)wy < (unsigned)c.wh1 && (unsigned)wx < (unsigned)c.ww1;
+                const bool fine = FG && c.l == 0;             // level 0 without a window: global corner offsets instead
                 if (inside && !inwin && !fine) fbm |= 1u << p;
                 const float a = sa[p], hh = 1.f - lh, hw = 1.f - lw;
                 // reading order: column sw first (sw = parity of the top-left row ^ octet class), see the header
-                const int rl = my_row0[p] + wy * my_ww[p] + wx;      // window row of the top-left corner
+                const int rl = c.row0 + wy * c.ww + wx;      // window row of the top-left corner
                 const int sw = (rl ^ cls) & 1;
                 // first = (top, column sw), partner = (top, column !sw); the bottom rows follow at + pitch (an immediate in
                 // the loop).  A sample that is not served from the window reads the zero rows (also at + its pitch).
@@ -378,9 +422,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 if (fine && k < P) {
                     // {4 corner byte offsets (kOob: outside the level / no sample), 4 weights}: the plain kernel's record
                     const int h0 = (int)h0f, w0 = (int)w0f;
-                    const bool top = h0 >= 0, bot = h0 + 1 <= myH[p] - 1, lef = w0 >= 0, rig = w0 + 1 <= myW[p] - 1;
-                    const unsigned base = (unsigned)(myst[p] + h0 * myW[p] + w0) * row_bytes;      // may wrap for -1: unused then
-                    const unsigned wrow = (unsigned)myW[p] * row_bytes;
+                    const bool top = h0 >= 0, bot = h0 + 1 <= c.H - 1, lef = w0 >= 0, rig = w0 + 1 <= c.W - 1;
+                    const unsigned base = (unsigned)(c.st + h0 * c.W + w0) * row_bytes;      // may wrap for -1: unused then
+                    const unsigned wrow = (unsigned)c.W * row_bytes;
                     *reinterpret_cast<uint4 *>(orec + kFineAt + k * 32) = make_uint4(
                         inside && top && lef ? base : kOob, inside && top && rig ? base + row_bytes : kOob,
                         inside && bot && lef ? base + wrow : kOob, inside && bot && rig ? base + wrow + row_bytes : kOob);
@@ -388,16 +432,16 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         ? make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 if (k < KLP && !(FG && k < P)) {
-                    *reinterpret_cast<unsigned *>(orec + kOffAt + k * 4) = (first >> 4) | ((partner >> 4) << 16);
+                    *reinterpret_cast<unsigned *>(orec + kOffAt + (k - kRec0) * 4) = (first >> 4) | ((partner >> 4) << 16);
                     if (!GATHER) {
                         const float wl_t = inwin ? a * (hh * hw) : 0.f, wl_b = inwin ? a * (lh * hw) : 0.f;
                         const float wr_t = inwin ? a * (hh * lw) : 0.f, wr_b = inwin ? a * (lh * lw) : 0.f;
                         // weights in reading order: top sw, top !sw, bottom sw, bottom !sw
-                        *reinterpret_cast<float4 *>(orec + k * 16) = sw ? make_float4(wr_t, wl_t, wr_b, wl_b)
+                        *reinterpret_cast<float4 *>(orec + (k - kRec0) * 16) = sw ? make_float4(wr_t, wl_t, wr_b, wl_b)
                                                                         : make_float4(wl_t, wr_t, wl_b, wr_b);
                     } else {
                         // a NaN location must not leak through 0 * NaN: everything zero unless served from the window
-                        *reinterpret_cast<float4 *>(orec + k * 16) =
+                        *reinterpret_cast<float4 *>(orec + (k - kRec0) * 16) =
                             make_float4(inwin ? lw : 0.f, inwin ? lh : 0.f, inwin ? a : 0.f, __int_as_float(sw));
                     }
                 }
@@ -454,10 +498,14 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     unsigned off[4];
                     float lw, lh;
                     float px_ = sx[0], py_ = sy[0], a_ = sa[0];
-                    int H_ = myH[0], W_ = myW[0], st_ = myst[0];
+                    const LvlC c0 = lvlc(0);
+                    int H_ = c0.H, W_ = c0.W, st_ = c0.st;
 #pragma unroll
                     for (int pp = 1; pp < NPASS; ++pp)
-                        if (p == pp) { px_ = sx[pp]; py_ = sy[pp]; a_ = sa[pp]; H_ = myH[pp]; W_ = myW[pp]; st_ = myst[pp]; }
+                        if (p == pp) {
+                            const LvlC c = lvlc(pp);
+                            px_ = sx[pp]; py_ = sy[pp]; a_ = sa[pp]; H_ = c.H; W_ = c.W; st_ = c.st;
+                        }
                     sample_setup_oob(px_, py_, H_, W_, st_, row_bytes, off, lw, lh);
                     *reinterpret_cast<uint4 *>(orec + kSlotAt + 32 * sl) = make_uint4(off[0], off[1], off[2], off[3]);
                     *reinterpret_cast<float4 *>(orec + kSlotAt + 32 * sl + 16) = make_float4(lw, lh, a_, 0.f);
@@ -474,7 +522,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             };
             // ---- the first two out-of-window samples of every octet: corner loads issued NOW, consumed after the LDS loop
             //      (their latency hides behind it); further ones take the loop at the end
-            constexpr int kPre = TUNE % 10, kSB = TUNE / 10;
+            constexpr int kPre = TUNE % 10, kSB = (TUNE / 10) % 10;
             bool pact[kPre > 0 ? kPre : 1];
             int pk[kPre > 0 ? kPre : 1];
             float4 pg[kPre > 0 ? kPre : 1], pv[kPre > 0 ? kPre : 1][4];
@@ -502,10 +550,12 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             }
             // ---- level 0 without a window: its 4 x 4 corner rows come through the vector-memory path, issued now and
             //      consumed after the LDS loop (the two pipes work side by side)
-            float4 fv[FG ? 2 : 1][4], fw[FG ? 2 : 1];           // two samples in flight at a time (registers: 2 x 20)
+            constexpr int kFineN = (TUNE / 100) & 1 ? 1 : 2;      // level-0 samples in flight at a time (registers: 20 each)
+            constexpr int kFineGroups = P / kFineN, kFineStep = (KLP - P) / kFineGroups > 0 ? (KLP - P) / kFineGroups : 1;
+            float4 fv[FG ? kFineN : 1][4], fw[FG ? kFineN : 1];
             auto fine_issue = [&](int k0) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < kFineN; ++i) {
                     const uint4 o = *reinterpret_cast<const uint4 *>(orec + kFineAt + (k0 + i) * 32);
                     fw[i] = *reinterpret_cast<const float4 *>(orec + kFineAt + (k0 + i) * 32 + 16);
                     fv[i][0] = buf_ld4(vr, o.x + lane_b);
@@ -516,7 +566,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             };
             auto fine_consume = [&]() {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < kFineN; ++i) {
                     acc.x = fmaf(fw[i].w, fv[i][3].x, fmaf(fw[i].z, fv[i][2].x, fmaf(fw[i].y, fv[i][1].x, fmaf(fw[i].x, fv[i][0].x, acc.x))));
                     acc.y = fmaf(fw[i].w, fv[i][3].y, fmaf(fw[i].z, fv[i][2].y, fmaf(fw[i].y, fv[i][1].y, fmaf(fw[i].x, fv[i][0].y, acc.y))));
                     acc.z = fmaf(fw[i].w, fv[i][3].z, fmaf(fw[i].z, fv[i][2].z, fmaf(fw[i].y, fv[i][1].z, fmaf(fw[i].x, fv[i][0].z, acc.z))));
@@ -530,8 +580,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
 #pragma unroll
                 for (int k = FG ? P : 0; k < KLP; ++k) {
                     const int pitch = Wn::ww(k / P) * 128;
-                    const float4 r = *reinterpret_cast<const float4 *>(orec + k * 16);
-                    const unsigned o = *reinterpret_cast<const unsigned *>(orec + kOffAt + k * 4);
+                    const float4 r = *reinterpret_cast<const float4 *>(orec + (k - kRec0) * 16);
+                    const unsigned o = *reinterpret_cast<const unsigned *>(orec + kOffAt + (k - kRec0) * 4);
                     const char *a0 = wbase + ((o & 0xffffu) << 4), *a1 = wbase + ((o >> 16) << 4);
                     const float4 f1 = *reinterpret_cast<const float4 *>(a0);
                     const float4 f2 = *reinterpret_cast<const float4 *>(a1);
@@ -543,7 +593,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         acc.z = fmaf(r.w, f4.z, fmaf(r.z, f3.z, fmaf(r.y, f2.z, fmaf(r.x, f1.z, acc.z))));
                         acc.w = fmaf(r.w, f4.w, fmaf(r.z, f3.w, fmaf(r.y, f2.w, fmaf(r.x, f1.w, acc.w))));
                         if (k % kSB == kSB - 1) __builtin_amdgcn_sched_barrier(0);      // bounds the registers of the unrolled loop
-                        if (FG && k == (P + KLP) / 2 - 1) { fine_consume(); fine_issue(2); __builtin_amdgcn_sched_barrier(0); }
+                        if (FG && (k - P) % kFineStep == kFineStep - 1 && (k - P) / kFineStep < kFineGroups - 1) {
+                            fine_consume();
+                            fine_issue(((k - P) / kFineStep + 1) * kFineN);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     } else {
                         const bool sw = __float_as_int(r.w) != 0;
                         const float4 vtl = sw ? f2 : f1, vtr = sw ? f1 : f2, vbl = sw ? f4 : f3, vbr = sw ? f3 : f4;
@@ -554,7 +608,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 }
             }
             if (FG) {
-                if (plain_round || DBG == 3) { fine_consume(); fine_issue(2); }      // the LDS loop (and its mid-point) was skipped
+                if (plain_round || DBG == 3) {      // the LDS loop (and its hand-over points) was skipped
+#pragma unroll
+                    for (int g = 1; g < kFineGroups; ++g) { fine_consume(); fine_issue(g * kFineN); }
+                }
                 fine_consume();
             }
             lap(7);                                // 7: compute loop (LDS)
@@ -629,8 +686,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     for (int p = 0; p < NPASS; ++p) {
                         const int k = j8 + 8 * p;
                         if (k < KLP) {
-                            const float4 res = make_float4(m_a[p], m_x[p] * (float)myW[p], m_y[p] * (float)myH[p], sa[p]);
-                            io.store_with_dot(row_c, nq_c, KLP, k, myl[p], P, myH[p], myW[p], res, dot);
+                            const LvlC c = lvlc(p);
+                            const float4 res = make_float4(m_a[p], m_x[p] * (float)c.W, m_y[p] * (float)c.H, sa[p]);
+                            io.store_with_dot(row_c, nq_c, KLP, k, c.l, P, c.H, c.W, res, dot);
                         }
                     }
                 }

@@ -54,8 +54,8 @@ def test_product_code_object_holds_only_reachable_msda_kernels():
                    "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "stream_kernel", "msda_bwd_own_merged",
                    "msda_fwd_d32_ws", "msda_bwd_lvl_mergedI", "msda_bwd_enc_fused_d32"):
         assert banned not in syms, banned
-    rw = sorted(n for n in names if "msda_rw_d32" in n)       # LocAttnIO + RawIO instantiation of <512, 16, 16, -1, 6, 4, forward>
-    assert len(rw) == 2 and all("Li512ELi16ELi16ELin1ELi6ELi4ELb0E" in n for n in rw), rw
+    rw = sorted(n for n in names if "msda_rw_d32" in n)       # LocAttnIO + RawIO instantiation of <768, 16, 16, -1, 6, 4, forward>
+    assert len(rw) == 2 and all("Li768ELi16ELi16ELin1ELi6ELi4ELb0E" in n for n in rw), rw
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(csrc, "libsemidetr_hip.so")],
                                           capture_output=True, text=True).stdout
     assert kernels >= {"msda_fwd_d32", "msda_rw_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged_wide",

@@ -28,6 +28,7 @@ def main():
                     help="encoder forward kernel (semidetr_msda_set_forward_policy)")
     ap.add_argument("--settle", type=int, default=0, help="synchronised warm-up launches (lets the adaptive forward policy see the data)")
     ap.add_argument("--cold", type=int, default=1, help="rotate this many distinct input sets (8 x 47 MB > the Infinity Cache)")
+    ap.add_argument("--check", action="store_true", help="forward only: compare the forced variant's result with the patch kernel's")
     a = ap.parse_args()
     import semi_detr_amd as sda
     import MultiScaleDeformableAttention as MSDA
@@ -61,6 +62,12 @@ def main():
     def pick():
         turn[0] += 1
         return sets[turn[0] % len(sets)]
+    if a.check:
+        out_v = MSDA.ms_deform_attn_forward(value, shapes, starts, loc, attn, 64)
+        sda._lib.set_variant(0, 0)
+        out_0 = MSDA.ms_deform_attn_forward(value, shapes, starts, loc, attn, 64)
+        sda._lib.set_variant(a.variant if a.fvariant is None else a.fvariant, a.variant)
+        print(f"CHECK max |variant - patch| = {(out_v - out_0).abs().max().item():.3e} (max |out| {out_0.abs().max().item():.3e})")
     runs = []
     if a.dir in ("fwd", "both"):
         def f():
