@@ -64,6 +64,9 @@ constexpr int kMaxLevels = 32;
                                  // flight instead of two (-33 VGPRs) + 200: level constants re-selected where they are used and staging
                                  // coordinates rebuilt per region instead of living in registers (256 -> 160 VGPRs: what lets 768 threads run)
 #endif
+#ifndef SEMIDETR_RW_TUNE5
+#define SEMIDETR_RW_TUNE5 310    // ... the five-level instantiation: ONE sample between scheduling barriers (three passes of samples per lane)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // sample geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 corner validity)
@@ -389,6 +392,8 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 constexpr float kFarToWindow = 0.46f;      // patch -> window when fewer than this share of the samples are far ...
 constexpr float kFarToWindowOneImage = 0.28f;      // a launch of ONE image takes the window kernel only below this share (sigma ~2.8 px)
 constexpr float kFarToPatch = 0.55f;       // ... window -> patch above this one (the kernels are level at ~0.53: sigma 4 px)
+// five levels (COCO-Full pyramid): margin 4 instead of 6 is what fits, the kernels are level at sigma ~3.8 px = a far share of ~0.49
+constexpr float kFarToWindow5 = 0.40f, kFarToPatch5 = 0.49f;
 struct FwdAdapt {
     unsigned *dev_cnt = nullptr;           // device words: {far, total, kind, -} x launch parity, [8] = publications so far
     unsigned *pub_host = nullptr;          // mapped pinned memory {sequence, far, total, kind}
@@ -404,7 +409,7 @@ FwdAdapt g_adapt[kMaxDevices];
 std::atomic<int> g_fwd_policy{0};          // 0 adaptive, 1 always the patch kernel, 2 the window kernel whenever it applies
 
 // the launch's FwdStats and the kernel to use; called with the stream the launch goes to
-int fwd_adapt_next(hipStream_t st, bool allow_window, int batch, FwdStats &fs, bool &use_window)
+int fwd_adapt_next(hipStream_t st, bool allow_window, int batch, int levels, FwdStats &fs, bool &use_window)
 {
     fs = FwdStats{nullptr, nullptr, nullptr, nullptr};
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
@@ -440,8 +445,8 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int batch, FwdStats &fs, b
                 a.seen_seq = seq;
                 a.last_frac = (float)far / (float)total;
                 ++a.updates;
-                if (a.mode == 0 && a.last_frac < kFarToWindow) a.mode = 1;
-                else if (a.mode == 1 && a.last_frac > kFarToPatch) a.mode = 0;
+                if (a.mode == 0 && a.last_frac < (levels == 5 ? kFarToWindow5 : kFarToWindow)) a.mode = 1;
+                else if (a.mode == 1 && a.last_frac > (levels == 5 ? kFarToPatch5 : kFarToPatch)) a.mode = 0;
             }
         }
         if (!capturing) {                              // a captured launch keeps the kernel of the moment and counts nothing
@@ -468,30 +473,36 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
     hipLaunchKernelGGL((msda_fwd_d32<SP, 4, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        (LDS), st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
     if (pixels) {
-        // encoder self-attention.  The region-window kernel is built for num_point == 4 and four levels and takes no padding
-        // mask (its windows are staged from `value` as it is).  One image alone fills the chip less well (616 regions x heads for
-        // 256 CUs): there it is ahead of the patch kernel up to sigma ~3 px instead of ~3.6 px (61 vs 67 us at 2 px)
-        const bool window_ok = P == kPT && L == 4 && !io.has_mask();
+        // encoder self-attention.  The region-window kernel is built for num_point == 4 and four or five levels and takes no
+        // padding mask (its windows are staged from `value` as it is).  One image alone fills the chip less well (616 regions x
+        // heads for 256 CUs): there it is ahead of the patch kernel up to sigma ~3 px instead of ~3.6 px (61 vs 67 us at 2 px)
+        const bool window_ok = P == kPT && (L == 4 || L == 5) && !io.has_mask();
         FwdStats fs;
         bool use_window = false;
-        if (int rc = fwd_adapt_next(st, window_ok, N, fs, use_window)) return rc;
+        if (int rc = fwd_adapt_next(st, window_ok, N, L, fs, use_window)) return rc;
         if (use_window) {
-            // 16 x 16 regions, level 0 through global loads, windows of the three coarse levels with a margin of SIX pixels: 123 KB of
-            // windows + 34.5 KB of octet records = one workgroup per CU either way, so the widest margin that fits is the best one
-            // (margin 4 / 5 / 6 at sigma 2 px: 239 / 231 / 219-229 us, at 3 px: 290 / 265 / 252 us) and the workgroup is as large as its
-            // registers allow (SEMIDETR_RW_NT above)
-            auto kern = &msda_rw_d32<IO, SEMIDETR_RW_NT, 16, 16, -1, 6, 4, false, 0, SEMIDETR_RW_TUNE>;
-            constexpr size_t wlds = rw_lds_bytes<SEMIDETR_RW_NT, 16, 16, -1, 6, 4>();
-            static_assert(wlds <= 160 * 1024, "region-window configuration does not fit the LDS");
-            if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
-            // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
-            // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
-            const int wbound = ((S * 3 / 4 + 255) / 256) * 9 / 8 + 2 * L;
-            SEMIDETR_REQUIRE((int64_t)N * wbound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
-            hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(SEMIDETR_RW_NT), wlds, st, (const float *)nullptr, value,
-                               spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs);
-            g_last_kernels = "msda_rw_d32";
-            return semidetr::launch_status("msda_rw_d32<forward>");
+            // 16 x 16 regions, level 0 through global loads, windows of the coarse levels with the widest margin that fits beside the
+            // octet records: one workgroup per CU either way, and the workgroup as large as its registers allow (SEMIDETR_RW_NT).
+            //   four levels: margin SIX, 123 KB of windows + 34.5 KB of records (margin 4 / 5 / 6 at sigma 2 px: 239 / 231 / 219-229 us,
+            //                at 3 px: 290 / 265 / 252 us)
+            //   five levels: margin FOUR (89 + 42 KB; margin 5 fits only a 640-thread workgroup: 251 against 234 us at 2 px), one
+            //                sample between scheduling barriers (three passes of samples per lane: two spill at 168 VGPRs);
+            //                patch kernel 317 / 291 / 300 us at sigma 1 / 2 / 3 px, this one 220 / 234 / 276
+            auto launch_window = [&](auto kern, size_t wlds) -> int {
+                if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
+                // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
+                // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
+                const int wbound = ((S * 3 / 4 + 255) / 256) * 9 / 8 + 2 * L;
+                SEMIDETR_REQUIRE((int64_t)N * wbound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
+                hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(SEMIDETR_RW_NT), wlds, st, (const float *)nullptr,
+                                   value, spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs);
+                g_last_kernels = "msda_rw_d32";
+                return semidetr::launch_status("msda_rw_d32<forward>");
+            };
+            constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, 16, 16, -1, 6, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT, 16, 16, -1, 4, 5>();
+            static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
+            if (L == 4) return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, 16, 16, -1, 6, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4);
+            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, 16, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5);
         }
         // 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges
         // included); a workgroup takes patches slot, slot + hint, ... so any hint >= 1 is correct

@@ -77,6 +77,9 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
     if constexpr (KL == 5 && !GATHER) {      // round 4: the product's shape for five levels (level 0 global, 16 x 16 regions)
         if (cfg == 15) return RWT(512, 16, 16, -1, 4, 0, 20);
         if (cfg == 18) return RWT(512, 16, 16, -1, 5, 0, 20);
+        if (cfg == 34) return RWT(768, 16, 16, -1, 4, 0, 310);      // lean registers, 12 waves per CU (margin 5 does not fit beside 96 octets' records)
+        if (cfg == 35) return RWT(640, 16, 16, -1, 5, 0, 310);      // 10 waves, margin 5
+        if (cfg == 36) return RWT(512, 16, 16, -1, 5, 0, 320);
     }
     if constexpr (KL == 4) return RWT(512, 8, 16, 4, 5, 0, 40);
     else return RWT(512, 8, 16, 4, 4, 0, 40);      // five levels: the margin-5 windows do not fit 160 KB

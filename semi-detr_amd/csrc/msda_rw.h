@@ -86,14 +86,23 @@ constexpr size_t rw_lds_bytes()
 }
 
 // smallest q in [0, nq] with ((2 q + 1) * nb) / (2 * nq) >= bound  (the first pixel of a level with nq rows whose centre
-// maps into row >= bound of the nb-row grid level).  32-bit division unless the product needs more (levels > 32767 wide).
+// maps into row >= bound of the nb-row grid level), i.e. with (2 q + 1) * nb >= 2 * nq * bound.  One 32-bit division; levels so
+// large that the product needs more bits (> 32767 pixels wide) bisect instead -- a 64-bit division would put its ~40 registers
+// into the kernel's budget although it never runs.
 __device__ __forceinline__ int rw_first(int bound, int nq, int nb)
 {
     const unsigned long long a = 2ull * (unsigned)nq * (unsigned)bound;
-    unsigned cc;                                      // ceil(a / nb): 2 q + 1 >= cc
-    if ((a + (unsigned)nb) >> 32) cc = (unsigned)((a + (unsigned)nb - 1u) / (unsigned)nb);
-    else cc = ((unsigned)a + (unsigned)nb - 1u) / (unsigned)nb;
-    return min(nq, (int)(cc >> 1));
+    if (((a + (unsigned)nb) >> 32) == 0) {
+        const unsigned cc = ((unsigned)a + (unsigned)nb - 1u) / (unsigned)nb;      // ceil(a / nb): 2 q + 1 >= cc
+        return min(nq, (int)(cc >> 1));
+    }
+    int lo = 0, hi = nq;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if ((2ull * (unsigned)mid + 1ull) * (unsigned)nb >= a) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
 }
 
 // DBG (tuning builds only): 1 = per-phase cycle counts of wave 0 into g_dest_dbg, 2 = windows not staged (results
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             while (__any(gmask != 0)) {
                 // kTrip such samples per octet and trip (one slot each): 4 * kTrip corner loads in flight per lane, as in the
                 // plain kernels -- a trip costs one global round trip whatever it carries
-                constexpr int kTrip = 2;      // = the octet's slots (four per trip measured no better: 222 vs 216 us)
+                constexpr int kTrip = ((TUNE / 100) & 4) ? 1 : 2;      // <= the octet's slots (four per trip measured no better: 222 vs 216 us; TUNE + 400: one, 20 VGPRs less)
                 bool act2[kTrip];
                 int k2[kTrip];
 #pragma unroll

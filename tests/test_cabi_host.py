@@ -40,22 +40,24 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_product_code_object_holds_only_reachable_msda_kernels():
-    """the product library's MSDA code object = the kernels its dispatcher can reach (30: forward patch /
-    strips x 3 splits, region-window forward (round 4), generic, gather x 3, region scatter, 1024-thread merged level scatter
-    x 2, strips backward x 2 -- each for the reference contract and the fused prologue, + fp64 generic), none of the
-    rejected experiments -- of msda_rw_d32 only the ONE forward configuration the dispatcher launches."""
+    """the product library's MSDA code object = the kernels its dispatcher can reach (32: forward patch /
+    strips x 3 splits, region-window forward for four and for five levels (round 4), generic, gather x 3, region scatter,
+    1024-thread merged level scatter x 2, strips backward x 2 -- each for the reference contract and the fused prologue,
+    + fp64 generic), none of the rejected experiments -- of msda_rw_d32 only the TWO forward configurations the dispatcher
+    launches."""
     import subprocess
     csrc = os.path.join(ROOT, "semi-detr_amd", "csrc")
     syms = subprocess.run(["strings", "-a", os.path.join(csrc, "libsemidetr_hip.so")], capture_output=True, text=True).stdout
     kernels = set(re.findall(r"_ZN12_GLOBAL__N_1\d+(msda_[a-z0-9_]+)I[^\n]*?\.kd", syms))
     names = set(re.findall(r"(_ZN12_GLOBAL__N_1\d+msda_[A-Za-z0-9_]+)\.kd", syms))
-    assert 20 <= len(names) <= 32, sorted(names)
+    assert 20 <= len(names) <= 34, sorted(names)
     for banned in ("msda_bwd_dest_d32", "msda_fwd_d32_lw", "msda_fwd_d32_res", "msda_bwd_enc_merged", "msda_bwd_encreg_merged",
                    "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "stream_kernel", "msda_bwd_own_merged",
                    "msda_fwd_d32_ws", "msda_bwd_lvl_mergedI", "msda_bwd_enc_fused_d32"):
         assert banned not in syms, banned
-    rw = sorted(n for n in names if "msda_rw_d32" in n)       # LocAttnIO + RawIO instantiation of <768, 16, 16, -1, 6, 4, forward>
-    assert len(rw) == 2 and all("Li768ELi16ELi16ELin1ELi6ELi4ELb0E" in n for n in rw), rw
+    rw = sorted(n for n in names if "msda_rw_d32" in n)       # LocAttnIO + RawIO of <768, 16, 16, -1, 6, 4, forward> and <..., 4, 5, forward>
+    assert len(rw) == 4 and sum("Li768ELi16ELi16ELin1ELi6ELi4ELb0E" in n for n in rw) == 2 and \
+        sum("Li768ELi16ELi16ELin1ELi4ELi5ELb0E" in n for n in rw) == 2, rw
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(csrc, "libsemidetr_hip.so")],
                                           capture_output=True, text=True).stdout
     assert kernels >= {"msda_fwd_d32", "msda_rw_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged_wide",

@@ -3,8 +3,8 @@
 
   * parity: patch kernel (policy "patch") and region-window kernel (policy "window") against the CPU oracle on the same
     inputs -- small pyramids incl. ragged edges / far samples / samples outside the map, the full-size bs-4 encoder shape
-    for the reference contract AND the fused prologue, and bitwise-equal results where the window kernel does not apply
-    (padding mask, five levels);
+    for the reference contract AND the fused prologue (four levels and the five-level COCO-Full pyramid), and the patch
+    kernel's results where the window kernel does not apply (padding mask, six levels);
   * the adaptive policy: close samples move the dispatcher to the window kernel, far ones move it back, and what the
     library reports as launched is what the policy state says.
 """
@@ -55,6 +55,9 @@ def _case(shapes, N, mode, seed):
     ([(20, 27), (10, 14), (5, 7), (3, 4)], 3, "far"),           # samples anywhere: (almost) every sample leaves its window
     ([(37, 53), (19, 27), (10, 14), (5, 7)], 2, "wide"),        # ragged 16 x 16 regions, samples partly outside the map
     ([(16, 16), (16, 16), (15, 17), (2, 2)], 2, "near"),        # levels that are NOT a halving pyramid: any input is correct
+    ([(37, 53), (19, 27), (10, 14), (5, 7), (3, 4)], 2, "near"),    # five levels (COCO-Full pyramid): its own instantiation
+    ([(37, 53), (19, 27), (10, 14), (5, 7), (3, 4)], 2, "wide"),
+    ([(20, 27), (10, 14), (5, 7), (3, 4), (2, 2)], 3, "far"),
 ])
 def test_window_and_patch_forward_vs_oracle(shapes, N, mode):
     import MultiScaleDeformableAttention as MSDA
@@ -71,12 +74,14 @@ def test_window_and_patch_forward_vs_oracle(shapes, N, mode):
 
 
 @pytest.mark.parametrize("io", ["locattn", "raw"])
-def test_window_forward_full_size_vs_oracle(io):
-    """N = 4, Lq = S = 22 223 (the launch bench.py times), sigma 2 px: the window kernel against the oracle, every element,
-    for the reference contract and for the fused prologue (softmax + locations inside the kernel)."""
+@pytest.mark.parametrize("levels", [LEVELS, LEVELS + [(7, 11)]], ids=["four_levels", "five_levels"])
+def test_window_forward_full_size_vs_oracle(io, levels):
+    """N = 4, Lq = S = 22 223 (the launch bench.py times) and the five-level COCO-Full pyramid (S = 22 300), sigma 2 px: the
+    window kernel against the oracle, every element, for the reference contract and for the fused prologue (softmax +
+    locations inside the kernel)."""
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd as sda
-    value, shp, ref, off, logits, _ = _encoder_case(4, LEVELS, 2.0, 21)
+    value, shp, ref, off, logits, _ = _encoder_case(4, levels, 2.0, 21)
     loc, attn = _prologue_np(ref, off, logits, shp, P)
     want = oracle.msda_forward(value, shp, loc, attn)
     tsh = _t(shp)
@@ -90,7 +95,7 @@ def test_window_forward_full_size_vs_oracle(io):
 
 
 def test_window_policy_keeps_the_patch_kernel_where_the_window_kernel_does_not_apply():
-    """Five levels, three points, a padding mask: policy "window" must fall back to the patch kernel (and give its results)."""
+    """Six levels, a padding mask: policy "window" must fall back to the patch kernel (and give its results)."""
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd as sda
     sda._lib.set_forward_policy("window")
@@ -99,7 +104,7 @@ def test_window_policy_keeps_the_patch_kernel_where_the_window_kernel_does_not_a
     out = MSDA.ms_deform_attn_forward(_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)
     assert _last() == "msda_rw_d32", _last()
     np.testing.assert_allclose(out.cpu().numpy(), oracle.msda_forward(value, shp, loc, attn), rtol=0, atol=2e-6)
-    for shapes, N in (([(20, 27), (10, 14), (5, 7), (3, 4), (2, 2)], 2),):
+    for shapes, N in (([(20, 27), (10, 14), (5, 7), (3, 4), (2, 2), (1, 1)], 2),):
         value, shp, loc, attn = _case(shapes, N, "near", 9)
         tsh = _t(shp)
         out = MSDA.ms_deform_attn_forward(_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)

@@ -24,19 +24,19 @@ def demangle(names):
 def main():
     path = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    cur, cnt, meta = None, collections.defaultdict(collections.Counter), collections.defaultdict(dict)
+    cur, mcur, cnt, meta = None, None, collections.defaultdict(collections.Counter), collections.defaultdict(dict)
     for line in open(path):
         m = re.match(r"^(_Z\w+):", line)
         if m:
             cur = m.group(1)
             continue
-        m = re.match(r"^\s*\.(vgpr_count|sgpr_count|vgpr_spill_count|agpr_count):\s*(\d+)", line)
+        m = re.match(r"^\s*\.name:\s*(_Z\w+)", line)      # metadata: .name precedes the entry's register counts
         if m:
-            meta["__last"][m.group(1)] = int(m.group(2))
+            mcur = m.group(1)
             continue
-        m = re.match(r"^\s*\.name:\s*(_Z\w+)", line)
-        if m and "__last" in meta:
-            meta[m.group(1)].update(meta.pop("__last"))
+        m = re.match(r"^\s*\.(vgpr_count|sgpr_count|vgpr_spill_count|sgpr_spill_count|group_segment_fixed_size):\s*(\d+)", line)
+        if m and mcur:
+            meta[mcur][m.group(1)] = int(m.group(2))
             continue
         if cur and line.startswith("\t"):
             t = line.split()

@@ -17,7 +17,7 @@ S = int((shapes[:, 0] * shapes[:, 1]).sum())
 ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h, (torch.arange(w, device=dev) + 0.5) / w,
                                             indexing="ij"), -1).flip(-1).reshape(-1, 2) for h, w in levels])
 sda._lib.set_forward_policy("patch")
-for sigma in (1.0, 2.0, 3.0):
+for sigma in [float(x) for x in os.environ.get("SIGMAS", "1.0 2.0 3.0").split()]:
     inv = torch.tensor([[sigma / w, sigma / h] for h, w in levels], device=dev).view(1, 1, 1, L, 1, 2)
     sets = []
     for _ in range(5):
