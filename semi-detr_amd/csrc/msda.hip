@@ -44,14 +44,16 @@ constexpr int kMaxLevels = 32;
 // A/B knobs of tools/r04_ab_multi.sh (same-box comparison of several builds inside the bench step).  Round 4, rotated inputs:
 // encoder gather with 8 instead of 16 corner loads in flight at five waves per SIMD: backward 701 -> 695 us at bs 4 (with
 // replayed inputs round 2 had measured it level); region scatter with 176 queries per pass at six waves per SIMD (three
-// workgroups per CU, 13 VGPRs spilled): 702 vs 701 us at bs 4, 205 vs 196 us at bs 1 -- not adopted.
+// workgroups per CU): with 13 VGPRs spilled 702 vs 701 us at bs 4, 205 vs 196 us at bs 1; once the thread-derived constants were
+// kept out of the kernel-long registers (msda_region.h: 102 -> 84 VGPRs at four waves, 2 spilled dwords at six) 700 -> 680 us at
+// bs 4, 197 -> 194.5 us at bs 1, fused prologue 733 -> 712 us -- adopted.
 #ifndef SEMIDETR_GATHER_WPE      // encoder gather: waves per SIMD the register budget is set for, corner loads in flight / 4
 #define SEMIDETR_GATHER_WPE 5
 #define SEMIDETR_GATHER_KB 2
 #endif
 #ifndef SEMIDETR_SCATTER_Q       // region scatter: queries per pass (LDS) and waves per SIMD
-#define SEMIDETR_SCATTER_Q 208
-#define SEMIDETR_SCATTER_WPE 4
+#define SEMIDETR_SCATTER_Q 176     // (a region of an 800 x 1333 pyramid has at most 171 queries: one pass; more take several)
+#define SEMIDETR_SCATTER_WPE 6
 #endif
 #ifndef SEMIDETR_RW_NT
 #define SEMIDETR_RW_NT 768       // msda_rw_d32: threads per workgroup.  Its windows take most of the LDS, so a CU holds ONE workgroup and

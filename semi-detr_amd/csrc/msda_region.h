@@ -55,7 +55,7 @@ __device__ __forceinline__ void reg_scatter_body(
     const int Lq = S, LP = L * P, rs = M * kD;
     const int m = (b % M + (b / M) / kScatterHeadRun) % M;
     const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid_k = threadIdx.x, tid = tid_k;
 
     // the finest level (most pixels) carries the region grid
     int lb = 0, Hb = (int)shapes[0], Wb = (int)shapes[1];
@@ -75,7 +75,14 @@ __device__ __forceinline__ void reg_scatter_body(
             tmark = now;
         }
     };
-    for (int reg = slot0; reg < nry * nrx; reg += regions_bound) {
+    const int Hb_k = Hb, Wb_k = Wb, nrx_k = nrx, nregions = nry * nrx;
+    for (int reg = slot0; reg < nregions; reg += regions_bound) {
+        // the thread index (again per pass below) and the region grid's sizes go through an empty asm: what is derived from them (LDS
+        // addresses, piece offsets, float copies, the reciprocal of the division below) is then rebuilt per region / pass instead of
+        // living in registers from the kernel's first instruction to its last (102 -> 90 VGPRs)
+        int tid_r = tid_k, Hb_p = Hb_k, Wb_p = Wb_k, nrx_p = nrx_k;
+        asm volatile("" : "+v"(tid_r), "+s"(Hb_p), "+s"(Wb_p), "+s"(nrx_p));
+        const int tid = tid_r, Hb = Hb_p, Wb = Wb_p, nrx = nrx_p;
         const int y0b = (reg / nrx) * RTH, x0b = (reg % nrx) * RTW;
         const int y1b = min(y0b + RTH, Hb), x1b = min(x0b + RTW, Wb);
         __syncthreads();                      // previous region fully done before its LDS state is reused
@@ -103,6 +110,9 @@ __device__ __forceinline__ void reg_scatter_body(
 
         for (int q_base = 0; q_base < nq_total; q_base += kRegQ) {      // one pass unless the region has > kRegQ queries
             const int nq = min(kRegQ, nq_total - q_base);
+            int tid_p = tid_k;
+            asm volatile("" : "+v"(tid_p));
+            const int tid = tid_p, lane = tid & 63, wv = tid >> 6;
             __syncthreads();
             for (int i = tid; i < nq; i += NT) {       // slot -> query index
                 int s = q_base + i, lq = 0;
