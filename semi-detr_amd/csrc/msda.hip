@@ -66,8 +66,12 @@ constexpr int kMaxLevels = 32;
                                  // flight instead of two (-33 VGPRs) + 200: level constants re-selected where they are used and staging
                                  // coordinates rebuilt per region instead of living in registers (256 -> 160 VGPRs: what lets 768 threads run)
 #endif
-#ifndef SEMIDETR_RW_TUNE5
-#define SEMIDETR_RW_TUNE5 310    // ... the five-level instantiation: ONE sample between scheduling barriers (three passes of samples per lane)
+#ifndef SEMIDETR_RW_NT5
+#define SEMIDETR_RW_NT5 1024     // ... the five-level instantiation: margin 4 is what fits either way, so the workgroup can be a full 1024 threads
+#define SEMIDETR_RW_TUNE5 1110   //     (16 waves per CU, 128 VGPRs): ONE sample between scheduling barriers (three passes of samples per lane) and
+                                 //     + 800: everything derived from the thread index rebuilt per round / region.  768 threads: 223 / 232 / 273 us
+                                 //     at sigma 1 / 2 / 3 px, 1024: 208 / 225 / 255.  (Four levels at 1024 threads would have to give up margin 6
+                                 //     for 5: 206 against 205 us -- no gain.)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -487,24 +491,24 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             // octet records: one workgroup per CU either way, and the workgroup as large as its registers allow (SEMIDETR_RW_NT).
             //   four levels: margin SIX, 123 KB of windows + 34.5 KB of records (margin 4 / 5 / 6 at sigma 2 px: 239 / 231 / 219-229 us,
             //                at 3 px: 290 / 265 / 252 us)
-            //   five levels: margin FOUR (89 + 42 KB; margin 5 fits only a 640-thread workgroup: 251 against 234 us at 2 px), one
-            //                sample between scheduling barriers (three passes of samples per lane: two spill at 168 VGPRs);
-            //                patch kernel 317 / 291 / 300 us at sigma 1 / 2 / 3 px, this one 220 / 234 / 276
-            auto launch_window = [&](auto kern, size_t wlds) -> int {
+            //   five levels: margin FOUR (89 + 56 KB; margin 5 fits only a 640-thread workgroup: 251 against 234 us at 2 px), 1024
+            //                threads; patch kernel 314 / 292 / 299 us at sigma 1 / 2 / 3 px, this one 208 / 225 / 255
+            auto launch_window = [&](auto kern, size_t wlds, int threads) -> int {
                 if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
                 // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
                 // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
                 const int wbound = ((S * 3 / 4 + 255) / 256) * 9 / 8 + 2 * L;
                 SEMIDETR_REQUIRE((int64_t)N * wbound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
-                hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(SEMIDETR_RW_NT), wlds, st, (const float *)nullptr,
+                hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(threads), wlds, st, (const float *)nullptr,
                                    value, spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs);
                 g_last_kernels = "msda_rw_d32";
                 return semidetr::launch_status("msda_rw_d32<forward>");
             };
-            constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, 16, 16, -1, 6, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT, 16, 16, -1, 4, 5>();
+            constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, 16, 16, -1, 6, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, 16, 16, -1, 4, 5>();
             static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
-            if (L == 4) return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, 16, 16, -1, 6, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4);
-            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, 16, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5);
+            if (L == 4)
+                return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, 16, 16, -1, 6, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4, SEMIDETR_RW_NT);
+            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, 16, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5);
         }
         // 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges
         // included); a workgroup takes patches slot, slot + hint, ... so any hint >= 1 is correct

@@ -56,7 +56,9 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         // TUNE + 100: one level-0 sample in flight instead of two; + 200: lean registers (level constants re-selected where they
         // are used, staging coordinates rebuilt per region) -- 160 instead of 256 VGPRs, which is what lets a 768-thread workgroup run
         case 30: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 0, 20); else break;
-        case 31: if constexpr (!GATHER) return RWT(1024, 16, 16, -1, 5, 0, 320); else break;     // 25 VGPRs spilled
+        case 31: if constexpr (!GATHER) return RWT(1024, 16, 16, -1, 5, 0, 1120); else break;    // + 800: everything thread-derived rebuilt per round / region: 125 VGPRs
+        case 40: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 1120); else break;
+        case 41: if constexpr (!GATHER) return RWT(1024, 16, 16, -1, 5, 0, 1110); else break;
         case 32: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 220); else break;      // the product shape, lean
         case 33: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 240); else break;      // ... four samples between barriers again
         case 34: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 320); else break;      // the PRODUCT configuration: 12 waves per CU, margin 6
@@ -80,6 +82,8 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         if (cfg == 34) return RWT(768, 16, 16, -1, 4, 0, 310);      // lean registers, 12 waves per CU (margin 5 does not fit beside 96 octets' records)
         if (cfg == 35) return RWT(640, 16, 16, -1, 5, 0, 310);      // 10 waves, margin 5
         if (cfg == 36) return RWT(512, 16, 16, -1, 5, 0, 320);
+        if (cfg == 40) return RWT(768, 16, 16, -1, 4, 0, 1120);
+        if (cfg == 41) return RWT(1024, 16, 16, -1, 4, 0, 1110);
     }
     if constexpr (KL == 4) return RWT(512, 8, 16, 4, 5, 0, 40);
     else return RWT(512, 8, 16, 4, 4, 0, 40);      // five levels: the margin-5 windows do not fit 160 KB

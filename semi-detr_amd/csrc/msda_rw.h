@@ -169,6 +169,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
 #pragma unroll
     for (int l = 0; l < KL; ++l)
         if (lane == l) { r_wh = Wn::wh(l); r_ww = Wn::ww(l); r_row0 = Wn::row0(l); }
+    const int r_H_k = r_H, r_W_k = r_W, r_st_k = r_st, r_wh_k = r_wh, r_ww_k = r_ww, r_row0_k = r_row0;      // (the region loop has its own)
     int Hs[KL], Ws[KL], sts[KL];
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
@@ -225,9 +226,35 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     char *const orec = recs + oc * kOctBytes;             // this octet's records
     const char *const wbase = lds + j8 * 16;
 
-    for (int reg = slot0; reg < nry * nrx; reg += regions_bound) {
+    const int Hb_k = Hb, Wb_k = Wb, nrx_k = nrx, nregions = nry * nrx;
+    for (int reg = slot0; reg < nregions; reg += regions_bound) {
+        int Hb_r = Hb_k, Wb_r = Wb_k, nrx_r = nrx_k;      // TUNE + 800: ... and the reciprocals of the divisions by these
+        if ((TUNE / 100) & 8) asm volatile("" : "+s"(Hb_r), "+s"(Wb_r), "+s"(nrx_r));
+        const int Hb = Hb_r, Wb = Wb_r, nrx = nrx_r;
         const int y0b = (reg / nrx) * RTH, x0b = (reg % nrx) * RTW;
         const int y1b = min(y0b + RTH, Hb), x1b = min(x0b + RTW, Wb);
+        // TUNE + 800: the per-level lane values are rebuilt per region from their wave-uniform copies (one select per level)
+        // instead of living in six registers from the kernel's first instruction on
+        int lane_t = tid;
+        if ((TUNE / 100) & 8) asm volatile("" : "+v"(lane_t));
+        const int lane_g = lane_t & 63;
+        int g_H = r_H_k, g_W = r_W_k, g_st = r_st_k, g_wh = r_wh_k, g_ww = r_ww_k, g_row0 = r_row0_k;
+        if ((TUNE / 100) & 8) {
+            g_H = g_W = g_wh = g_ww = 1;
+            g_st = g_row0 = 0;
+#pragma unroll
+            for (int l = 0; l < KL; ++l)
+                if (lane_g == l) {
+                    g_H = __builtin_amdgcn_readfirstlane(Hs[l]);
+                    g_W = __builtin_amdgcn_readfirstlane(Ws[l]);
+                    g_st = __builtin_amdgcn_readfirstlane(sts[l]);
+                    g_wh = Wn::wh(l);
+                    g_ww = Wn::ww(l);
+                    g_row0 = Wn::row0(l);
+                }
+        }
+        const int r_H = g_H, r_W = g_W, r_st = g_st, r_wh = g_wh, r_ww = g_ww, r_row0 = g_row0;
+        (void)r_row0;
         // ---- the region's queries: on level lq an exact rectangle (lanes 0 .. KL-1 of every wave work it out; the counts
         //      become wave-uniform through readlane, the rest is fetched per lane with __shfl: no LDS table, no barrier)
         int r_ylo = 0, r_xlo = 0, r_w = 1, r_cnt = 0;
@@ -287,8 +314,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         // raw sample data of a round: loaded one round ahead of its use
         float rx[NPASS], ry[NPASS], ra[NPASS];
         float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-        int q = slot_query(oc);
-        auto load_round = [&](int qq) {
+        int q = slot_query(lane_t >> 3);
+        auto load_round = [&](int qq, int j8) {      // (j8: the caller's copy -- the lean builds rebuild it per round)
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 const int k = j8 + 8 * p;
@@ -303,7 +330,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             if (GATHER && qq >= 0)
                 go = *reinterpret_cast<const float4 *>(gout + (((int64_t)n * Lq + qq) * M + m) * kD + 4 * j8);
         };
-        load_round(q);
+        load_round(q, lane_t & 7);
 
         lap(0);                            // 0: region set-up (rectangles, round-0 loads issued)
         // ---- stage the windows through registers: all loads of a thread first, then its stores
@@ -311,8 +338,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             constexpr int RPS = NT / 8;                                   // window rows covered per step (8 lanes per row)
             constexpr int kMaxSteps = (Wn::zrow + RPS - 1) / RPS + KL;
             float4 sv[kMaxSteps];
-            int ocs = oc;      // lean builds: the per-thread window coordinates below are rebuilt per region, not kept in registers
-            if (kLean) asm volatile("" : "+v"(ocs));
+            int tids = tid;    // lean builds: the per-thread window coordinates below are rebuilt per region, not kept in registers
+            if (kLean) asm volatile("" : "+v"(tids));
+            const int ocs = tids >> 3, j8s = tids & 7;
+            const unsigned lane_bs = (unsigned)(m * kD + 4 * j8s) * 4u;
             if (DBG != 2) {
                 int nst = 0;
 #pragma unroll
@@ -323,7 +352,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
                         const int py = wy0[l] + wy, px = wx0[l] + wx;
                         const bool ok = r < rows_ && (unsigned)py < (unsigned)Hs[l] && (unsigned)px < (unsigned)Ws[l];
-                        const unsigned goff = ok ? (unsigned)(sts[l] + py * Ws[l] + px) * row_bytes + lane_b : kOob;
+                        const unsigned goff = ok ? (unsigned)(sts[l] + py * Ws[l] + px) * row_bytes + lane_bs : kOob;
                         sv[nst++] = buf_ld4(vr, goff);
                         r += RPS;
                         wx += RPS % ww_;
@@ -343,20 +372,32 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     int r = ocs;
 #pragma unroll
                     for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
-                        if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8 * 16) = sv[ist];
+                        if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8s * 16) = sv[ist];
                         ++ist;
                         r += RPS;
                     }
                 }
             }
-            if (oc < Wn::zrows)
-                *reinterpret_cast<float4 *>(lds + kZ0 + oc * 128 + j8 * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ocs < Wn::zrows) {
+                float z = 0.f;
+                if (kLean) asm volatile("" : "+v"(z));      // (a zero the compiler cannot keep in four registers for the whole kernel)
+                *reinterpret_cast<float4 *>(lds + kZ0 + ocs * 128 + j8s * 16) = make_float4(z, z, z, z);
+            }
         }
         lap(3);                            // 3: windows stored (incl. the wait for the staging loads)
         __syncthreads();                   // the windows are complete
         lap(4);                            // 4: waiting for the other waves' stores
 
         for (int round = 0; round < nrounds; ++round) {
+            // TUNE + 800: the thread index goes through an empty asm once per round, so that what is derived from it (octet and
+            // window addresses, the lane's byte offset) is rebuilt here instead of living in registers through the whole kernel
+            int tid_r = tid;
+            if ((TUNE / 100) & 8) asm volatile("" : "+v"(tid_r));
+            const int oc = tid_r >> 3, j8 = tid_r & 7, cls = (tid_r >> 4) & 1, lane = tid_r & 63;
+            const unsigned lane_b = (unsigned)(m * kD + 4 * j8) * 4u;
+            char *const orec = recs + oc * kOctBytes;
+            const char *const wbase = lds + j8 * 16;
+            (void)lane;
             // ---- geometry of my samples -> records
             float sx[NPASS], sy[NPASS], sa[NPASS];
             const float4 mygo = go;
@@ -459,7 +500,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             lap(5);                                // 5: geometry + record writes (incl. the wait for the round's raw data)
             // ---- next round's raw data (its latency hides behind this round's compute)
             q = slot_query((round + 1) * G + oc);
-            if (round + 1 < nrounds) load_round(q);
+            if (round + 1 < nrounds) load_round(q, j8);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my wave's records are written
 
             // out-of-window samples of this wave: per octet a mask over (pass, lane)
