@@ -61,10 +61,12 @@ constexpr int kMaxLevels = 32;
                                  // (1024 threads: only with margin 5 and 25 spilled registers so far, 262 us)
 #endif
 #ifndef SEMIDETR_RW_TUNE
-#define SEMIDETR_RW_TUNE 320     // msda_rw_d32: 10 x compute-loop samples between scheduling barriers (two: with four samples' LDS reads
+#define SEMIDETR_RW_TUNE 1920    // msda_rw_d32: 10 x compute-loop samples between scheduling barriers (two: with four samples' LDS reads
                                  // in flight round 4's first version spilled; one: 2 us slower) + 100: one level-0 sample's corner loads in
                                  // flight instead of two (-33 VGPRs) + 200: level constants re-selected where they are used and staging
                                  // coordinates rebuilt per region instead of living in registers (256 -> 160 VGPRs: what lets 768 threads run)
+                                 // + 1600: the fused prologue's location arithmetic at the start of the round that uses the loaded data, not
+                                 // where the loads are issued (a round early, waiting for them): fused-prologue forward 189.8 -> 188.0 us
 #endif
 #ifndef SEMIDETR_RW_NT5
 #define SEMIDETR_RW_NT5 1024     // ... the five-level instantiation: margin 4 is what fits either way, so the workgroup can be a full 1024 threads

@@ -61,6 +61,19 @@ struct LocAttnIO {
         x = xy.x;
         y = xy.y;
     }
+    // two-step form for callers that load a round ahead: what the loads return, and the arithmetic that turns it into (x, y)
+    struct RawXY { float2 xy; };
+    __device__ __forceinline__ RawXY load_xy_raw(int64_t row, int64_t nq, int LP, int k, int l) const
+    {
+        (void)nq; (void)l;
+        return RawXY{ld_stream2(loc + (row * LP + k) * 2)};
+    }
+    __device__ __forceinline__ void finish_xy_raw(const RawXY &r, int P, int H, int W, float &x, float &y) const
+    {
+        (void)P; (void)H; (void)W;
+        x = r.xy.x;
+        y = r.xy.y;
+    }
     __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return ld_stream1(attn + row * LP + k); }
     // res = {d/d attn, d/d loc.x, d/d loc.y, attn} of sample k; row_res = the LP results of the same (n,q,m) row
     __device__ __forceinline__ void store(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
@@ -122,6 +135,15 @@ struct RawIO {
         const float2 o = ld_stream2(off + (row * LP + k) * 2);
         const float4 r = buf_ld4(image_rsrc(ref, ref_bytes), (unsigned)((nq * L + l) * ref_dim) * 4u);
         finish_xy(o, r, P, H, W, x, y);
+    }
+    struct RawXY { float2 o; float4 r; };      // offset and reference point as loaded (see LocAttnIO::RawXY)
+    __device__ __forceinline__ RawXY load_xy_raw(int64_t row, int64_t nq, int LP, int k, int l) const
+    {
+        return RawXY{ld_stream2(off + (row * LP + k) * 2), buf_ld4(image_rsrc(ref, ref_bytes), (unsigned)((nq * L + l) * ref_dim) * 4u)};
+    }
+    __device__ __forceinline__ void finish_xy_raw(const RawXY &r, int P, int H, int W, float &x, float &y) const
+    {
+        finish_xy(r.o, r.r, P, H, W, x, y);
     }
     __device__ __forceinline__ void finish_xy(const float2 o, const float4 r, int P, int H, int W, float &x, float &y) const
     {

@@ -312,6 +312,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             return ok ? st_ + (yl + dy) * W_ + xl + (s - dy * w_) : -1;
         };
         // raw sample data of a round: loaded one round ahead of its use
+        // (TUNE + 1600: the loads' results stay as they arrive and the location arithmetic of the fused prologue runs at the START of
+        //  the round that uses them -- done where the loads are issued it waits for them a round early)
+        constexpr bool kSplitLoad = ((TUNE / 100) & 16) != 0;
+        typename IO::RawXY rr[NPASS];
         float rx[NPASS], ry[NPASS], ra[NPASS];
         float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
         int q = slot_query(lane_t >> 3);
@@ -323,7 +327,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 if (qq >= 0 && k < KLP) {
                     const int64_t nq = (int64_t)n * Lq + qq, row = nq * M + m;
                     const LvlC c = lvlc(p);
-                    io.load_xy(row, nq, KLP, k, c.l, P, c.H, c.W, rx[p], ry[p]);
+                    if constexpr (kSplitLoad) rr[p] = io.load_xy_raw(row, nq, KLP, k, c.l);
+                    else io.load_xy(row, nq, KLP, k, c.l, P, c.H, c.W, rx[p], ry[p]);
                     ra[p] = io.load_w(row, KLP, k);
                 }
             }
@@ -404,8 +409,16 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             unsigned fbm = 0;                     // bit p: my sample of pass p is valid but leaves its window
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
-                sx[p] = rx[p];
-                sy[p] = ry[p];
+                if constexpr (kSplitLoad) {
+                    sx[p] = sy[p] = 0.f;
+                    if (q >= 0 && j8 + 8 * p < KLP) {
+                        const LvlC c = lvlc(p);
+                        io.finish_xy_raw(rr[p], P, c.H, c.W, sx[p], sy[p]);
+                    }
+                } else {
+                    sx[p] = rx[p];
+                    sy[p] = ry[p];
+                }
                 sa[p] = ra[p];
             }
             if (IO::kSoftmax) {
