@@ -775,8 +775,8 @@ def cpu_baseline(wl=None):
 
 
 def forward_policy_bench(dev, iters=24, nsets=4):
-    """Encoder self-attention forward at bs 4 (the step's dominant launch) by how far the samples reach: sigma = 1 / 2 / 4 px of
-    the sampled level, rotated input sets, under the three policies of semidetr_msda_set_forward_policy.  `adaptive` is
+    """Encoder self-attention forward at bs 4 (the step's dominant launch) by how far the samples reach: sigma = 1 / 2 / 4 / 6 px of
+    the sampled level (the kernels are level at ~5.5 px), rotated input sets, under the three policies of semidetr_msda_set_forward_policy.  `adaptive` is
     timed after the dispatcher has seen the data (a few synchronised launches); it must sit on the faster kernel's time."""
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd as sda
@@ -786,7 +786,7 @@ def forward_policy_bench(dev, iters=24, nsets=4):
                                                 indexing="ij"), -1).flip(-1).reshape(-1, 2) for h, w in LEVELS])
     n, res = 4, {}
     g = torch.Generator(device=dev).manual_seed(99)
-    for sigma in (1.0, 2.0, 4.0):
+    for sigma in (1.0, 2.0, 4.0, 6.0):
         inv = torch.tensor([[sigma / w, sigma / h] for h, w in LEVELS], device=dev).view(1, 1, 1, L, 1, 2)
         sets = []
         for _ in range(nsets):

@@ -123,18 +123,18 @@ int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const 
                                      float *grad_sampling_offsets, float *grad_attn_logits);
 
 /* ---------------------------------------------------------------------------------------------
- * Which kernel runs the encoder self-attention FORWARD (SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, four levels, no
- * padding mask).  The reference has one kernel for everything (ms_deform_im2col_cuda.cuh:237-299); here two
+ * Which kernel runs the encoder self-attention FORWARD (SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, four or five levels,
+ * no padding mask).  The reference has one kernel for everything (ms_deform_im2col_cuda.cuh:237-299); here two
  * produce the same results at different speeds depending on how far the learned offsets reach:
  *   patch kernel   -- 4 x 8 query patches, every corner row through the vector-memory path; insensitive to the offsets
- *   window kernel  -- 16 x 16 regions, the coarse levels' corner rows from LDS windows +- 6 px around the region;
- *                     4-18 % faster while most samples stay inside, level with the patch kernel when half of them are
- *                     more than 4 px away (sigma 4 px), slower beyond
+ *   window kernel  -- 16 x 16 regions, the coarse levels' corner rows from LDS windows +- 6 px (five levels: +- 4 px) around
+ *                     the region; 10-25 % faster while most samples stay inside, level with the patch kernel when ~70 % of
+ *                     them are more than 4 px away (sigma ~5.5 px), slower beyond
  * policy 0 (default, adaptive): both kernels count, in a few workgroups, the share of samples further than 4 px from their
  *   query's pixel centre; launch k's count reaches the host through mapped pinned memory when launch k + 1 starts (no copy
  *   command, no synchronisation) and the NEXT dispatch on that device moves between the kernels with hysteresis (to the
- *   window kernel below 46 %, back above 55 %; a launch of a single image takes it only below 28 %).  State is per device; launches inside a stream capture keep the kernel of
- *   the moment and count nothing.
+ *   window kernel below 60 %, back above 70 %; five levels 56 % / 66 %).  State is per device; launches inside a stream
+ *   capture keep the kernel of the moment and count nothing.
  * policy 1: always the patch kernel.   policy 2: the window kernel whenever it applies.   (Process-wide.)
  * semidetr_msda_forward_policy_state: for the calling thread's current device -- the policy, the kernel the adaptive policy
  *   stands on (0 patch, 1 window), the last far-sample fraction received (-1: none yet), the number of counts received.

@@ -397,11 +397,13 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 //      handed to the host by the first thread of launch k + 1 through mapped pinned memory, and the dispatcher -- whenever it
 //      next gets here, it never waits -- moves between the kernels with hysteresis.  Per device; a mutex serialises the few
 //      host words.  semidetr_msda_set_forward_policy pins the choice (tests, A/B timing).
-constexpr float kFarToWindow = 0.46f;      // patch -> window when fewer than this share of the samples are far ...
-constexpr float kFarToWindowOneImage = 0.28f;      // a launch of ONE image takes the window kernel only below this share (sigma ~2.8 px)
-constexpr float kFarToPatch = 0.55f;       // ... window -> patch above this one (the kernels are level at ~0.53: sigma 4 px)
-// five levels (COCO-Full pyramid): margin 4 instead of 6 is what fits, the kernels are level at sigma ~3.8 px = a far share of ~0.49
-constexpr float kFarToWindow5 = 0.40f, kFarToPatch5 = 0.49f;
+// Thresholds re-measured with the 768 / 1024-thread window kernels (tools/r04_rw_cross2.sh, rotated inputs, bs 4): four levels 233 /
+// 243 / 251 / 261 / 283 us against the patch kernel's 270-273 us at sigma 3.5 / 4 / 4.5 / 5 / 6 px -- level at ~5.5 px = a far share of
+// ~0.71; five levels level at ~5 px = ~0.67.  One image alone (616 regions x heads for 256 CUs) used to need its own, lower bound;
+// the larger workgroups removed the difference (57 / 63 / 65.5 / 68.5 against 68 / 70.5 / 71.5 / 72 us at 2 / 3 / 3.5 / 4 px).
+constexpr float kFarToWindow = 0.60f;      // patch -> window when fewer than this share of the samples are far ...
+constexpr float kFarToPatch = 0.70f;       // ... window -> patch above this one
+constexpr float kFarToWindow5 = 0.56f, kFarToPatch5 = 0.66f;      // five levels (COCO-Full pyramid: margin 4 instead of 6)
 struct FwdAdapt {
     unsigned *dev_cnt = nullptr;           // device words: {far, total, kind, -} x launch parity, [8] = publications so far
     unsigned *pub_host = nullptr;          // mapped pinned memory {sequence, far, total, kind}
@@ -462,7 +464,8 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int batch, int levels, Fwd
             fs = FwdStats{a.dev_cnt + 4 * par, a.dev_cnt + 4 * (1 - par), a.pub_dev, a.dev_cnt + 8};
         }
     }
-    use_window = a.mode == 1 && (batch >= 2 || (a.last_frac >= 0.f && a.last_frac < kFarToWindowOneImage));
+    (void)batch;
+    use_window = a.mode == 1;
     return SEMIDETR_OK;
 }
 
@@ -482,8 +485,7 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
                        (LDS), st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
     if (pixels) {
         // encoder self-attention.  The region-window kernel is built for num_point == 4 and four or five levels and takes no
-        // padding mask (its windows are staged from `value` as it is).  One image alone fills the chip less well (616 regions x
-        // heads for 256 CUs): there it is ahead of the patch kernel up to sigma ~3 px instead of ~3.6 px (61 vs 67 us at 2 px)
+        // padding mask (its windows are staged from `value` as it is).
         const bool window_ok = P == kPT && (L == 4 || L == 5) && !io.has_mask();
         FwdStats fs;
         bool use_window = false;

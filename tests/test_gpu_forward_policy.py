@@ -125,7 +125,7 @@ def test_window_policy_keeps_the_patch_kernel_where_the_window_kernel_does_not_a
 
 
 def test_adaptive_policy_follows_the_sample_spread():
-    """Close samples (sigma 1 px) -> the dispatcher moves to the window kernel; far samples (sigma 6 px) -> back to the patch
+    """Close samples (sigma 1 px) -> the dispatcher moves to the window kernel; far samples (sigma 7 px) -> back to the patch
     kernel; results equal the oracle's throughout.  (The count of launch k reaches the host when launch k + 1 starts and is
     acted on by the dispatch after that, so a few launches with a synchronisation in between are needed: in training the
     host runs ahead and the choice simply lags by a step.)"""
@@ -154,9 +154,9 @@ def test_adaptive_policy_follows_the_sample_spread():
     k_close = run(1.0, 6)
     st1 = sda._lib.forward_policy_state()
     assert st1["updates"] > st0["updates"], (st0, st1)
-    assert st1["mode"] == 1 and 0.0 <= st1["far_fraction"] < 0.46, st1
+    assert st1["mode"] == 1 and 0.0 <= st1["far_fraction"] < 0.60, st1
     assert k_close[-1] == "msda_rw_d32", k_close
-    k_far = run(6.0, 6)
+    k_far = run(7.0, 6)
     st2 = sda._lib.forward_policy_state()
-    assert st2["mode"] == 0 and st2["far_fraction"] > 0.55, st2
+    assert st2["mode"] == 0 and st2["far_fraction"] > 0.70, st2
     assert k_far[0] == "msda_rw_d32" and k_far[-1] == "msda_fwd_d32<1, 4, 408", k_far
