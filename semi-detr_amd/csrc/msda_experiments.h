@@ -59,6 +59,9 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 31: if constexpr (!GATHER) return RWT(1024, 16, 16, -1, 5, 0, 1120); else break;    // + 800: everything thread-derived rebuilt per round / region: 125 VGPRs
         case 40: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 1120); else break;
         case 41: if constexpr (!GATHER) return RWT(1024, 16, 16, -1, 5, 0, 1110); else break;
+        case 42: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 5120); else break;     // + 3200: window addresses by v_mad_u32_u16, FMAs with explicit op_sel
+        case 43: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 1920); else break;     // the product configuration (= 734 + 1600)
+        case 44: if constexpr (!GATHER) return RWT(704, 16, 16, -1, 6, 0, 1920); else break;     // 11 waves: a region's 340 queries fill 3.86 rounds of 88
         case 32: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 220); else break;      // the product shape, lean
         case 33: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 240); else break;      // ... four samples between barriers again
         case 34: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 320); else break;      // the PRODUCT configuration: 12 waves per CU, margin 6
@@ -135,7 +138,7 @@ int exp_launch_fast_forward(hipStream_t st, const float *value, const int64_t *s
         g_last_kernels = "msda_fwd_d32_ws";
         return semidetr::launch_status("msda_fwd_d32_ws");
     }
-    if ((g_fwd_variant >= 700 && g_fwd_variant <= 719) || (g_fwd_variant >= 730 && g_fwd_variant <= 749)) {
+    if ((g_fwd_variant >= 700 && g_fwd_variant <= 719) || (g_fwd_variant >= 730 && g_fwd_variant <= 759)) {
         SEMIDETR_REQUIRE(pixels && P == kPT && (L == 4 || L == 5), SEMIDETR_E_BADARG,
                          "msda_forward: the region-window kernel needs SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, 4 or 5 levels");
         g_last_kernels = "msda_rw_d32";

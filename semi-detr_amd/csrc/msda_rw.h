@@ -105,6 +105,30 @@ __device__ __forceinline__ int rw_first(int bound, int nq, int nb)
     return lo;
 }
 
+// acc += w.x f1 + w.y f2 + w.z f3 + w.w f4 over four channels as eight v_pk_fma_f32 whose weight operand is one HALF of an aligned
+// register pair (op_sel): the compiler finds the low half (w.x, w.z) and the high half of the first pair (w.y), but copies w.w into
+// a fresh pair first -- two v_mov per sample, 24 per round of the window loop.  Same operation order per channel as the fmaf chain.
+typedef float rw_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rw_fma4(float4 &acc, const float4 &w, const float4 &f1, const float4 &f2, const float4 &f3,
+                                        const float4 &f4)
+{
+    rw_v2f a01 = {acc.x, acc.y}, a23 = {acc.z, acc.w};
+    const rw_v2f wxy = {w.x, w.y}, wzw = {w.z, w.w};
+#define RW_PK_LO(ACC, W, FX, FY) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(ACC) : "v"(W), "v"(rw_v2f{FX, FY}))
+#define RW_PK_HI(ACC, W, FX, FY) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(ACC) : "v"(W), "v"(rw_v2f{FX, FY}))
+    RW_PK_LO(a01, wxy, f1.x, f1.y);
+    RW_PK_LO(a23, wxy, f1.z, f1.w);
+    RW_PK_HI(a01, wxy, f2.x, f2.y);
+    RW_PK_HI(a23, wxy, f2.z, f2.w);
+    RW_PK_LO(a01, wzw, f3.x, f3.y);
+    RW_PK_LO(a23, wzw, f3.z, f3.w);
+    RW_PK_HI(a01, wzw, f4.x, f4.y);
+    RW_PK_HI(a23, wzw, f4.z, f4.w);
+#undef RW_PK_LO
+#undef RW_PK_HI
+    acc = make_float4(a01.x, a01.y, a23.x, a23.y);
+}
+
 // DBG (tuning builds only): 1 = per-phase cycle counts of wave 0 into g_dest_dbg, 2 = windows not staged (results
 // wrong, timing aid), 3 = compute loop skipped (results wrong, timing aid)
 // TUNE = 10 * (compute-loop steps between scheduling barriers) + (out-of-window samples per octet whose loads are issued
@@ -394,6 +418,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         lap(4);                            // 4: waiting for the other waves' stores
 
         for (int round = 0; round < nrounds; ++round) {
+            // queries are dealt out in order, so a wave without one in this round has none in the later ones either: it leaves the
+            // loop (no workgroup barrier inside) instead of spending issue slots on empty octets -- a region's 340 queries fill
+            // 3.5 rounds of 96
+            if (!__any(q >= 0)) break;
             // TUNE + 800: the thread index goes through an empty asm once per round, so that what is derived from it (octet and
             // window addresses, the lane's byte offset) is rebuilt here instead of living in registers through the whole kernel
             int tid_r = tid;
@@ -630,6 +658,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             auto fine_consume = [&]() {
 #pragma unroll
                 for (int i = 0; i < kFineN; ++i) {
+                    if constexpr (((TUNE / 100) & 32) != 0) {
+                        rw_fma4(acc, fw[i], fv[i][0], fv[i][1], fv[i][2], fv[i][3]);
+                        continue;
+                    }
                     acc.x = fmaf(fw[i].w, fv[i][3].x, fmaf(fw[i].z, fv[i][2].x, fmaf(fw[i].y, fv[i][1].x, fmaf(fw[i].x, fv[i][0].x, acc.x))));
                     acc.y = fmaf(fw[i].w, fv[i][3].y, fmaf(fw[i].z, fv[i][2].y, fmaf(fw[i].y, fv[i][1].y, fmaf(fw[i].x, fv[i][0].y, acc.y))));
                     acc.z = fmaf(fw[i].w, fv[i][3].z, fmaf(fw[i].z, fv[i][2].z, fmaf(fw[i].y, fv[i][1].z, fmaf(fw[i].x, fv[i][0].z, acc.z))));
@@ -645,16 +677,34 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     const int pitch = Wn::ww(k / P) * 128;
                     const float4 r = *reinterpret_cast<const float4 *>(orec + (k - kRec0) * 16);
                     const unsigned o = *reinterpret_cast<const unsigned *>(orec + kOffAt + (k - kRec0) * 4);
-                    const char *a0 = wbase + ((o & 0xffffu) << 4), *a1 = wbase + ((o >> 16) << 4);
+                    const char *a0, *a1;
+                    if constexpr (((TUNE / 100) & 32) != 0) {
+                        // TUNE + 3200: window address = base + 16 x (16-bit offset) as ONE v_mad_u32_u16 each (op_sel picks the half of
+                        // the packed word) instead of shift / mask / add: 2 instead of 5 VALU instructions per sample
+                        unsigned u0, u1;
+                        typedef const __attribute__((address_space(3))) char *lds_cptr;      // 32-bit LDS addresses, no base to add
+                        const unsigned jb = (unsigned)(uintptr_t)(lds_cptr)wbase;
+                        asm("v_mad_u32_u16 %0, %1, 16, %2" : "=v"(u0) : "v"(o), "v"(jb));
+                        asm("v_mad_u32_u16 %0, %1, 16, %2 op_sel:[1,0,0,0]" : "=v"(u1) : "v"(o), "v"(jb));
+                        a0 = (const char *)(lds_cptr)(uintptr_t)u0;
+                        a1 = (const char *)(lds_cptr)(uintptr_t)u1;
+                    } else {
+                        a0 = wbase + ((o & 0xffffu) << 4);
+                        a1 = wbase + ((o >> 16) << 4);
+                    }
                     const float4 f1 = *reinterpret_cast<const float4 *>(a0);
                     const float4 f2 = *reinterpret_cast<const float4 *>(a1);
                     const float4 f3 = *reinterpret_cast<const float4 *>(a0 + pitch);
                     const float4 f4 = *reinterpret_cast<const float4 *>(a1 + pitch);
                     if (!GATHER) {
-                        acc.x = fmaf(r.w, f4.x, fmaf(r.z, f3.x, fmaf(r.y, f2.x, fmaf(r.x, f1.x, acc.x))));
-                        acc.y = fmaf(r.w, f4.y, fmaf(r.z, f3.y, fmaf(r.y, f2.y, fmaf(r.x, f1.y, acc.y))));
-                        acc.z = fmaf(r.w, f4.z, fmaf(r.z, f3.z, fmaf(r.y, f2.z, fmaf(r.x, f1.z, acc.z))));
-                        acc.w = fmaf(r.w, f4.w, fmaf(r.z, f3.w, fmaf(r.y, f2.w, fmaf(r.x, f1.w, acc.w))));
+                        if constexpr (((TUNE / 100) & 32) != 0) {
+                            rw_fma4(acc, r, f1, f2, f3, f4);
+                        } else {
+                            acc.x = fmaf(r.w, f4.x, fmaf(r.z, f3.x, fmaf(r.y, f2.x, fmaf(r.x, f1.x, acc.x))));
+                            acc.y = fmaf(r.w, f4.y, fmaf(r.z, f3.y, fmaf(r.y, f2.y, fmaf(r.x, f1.y, acc.y))));
+                            acc.z = fmaf(r.w, f4.z, fmaf(r.z, f3.z, fmaf(r.y, f2.z, fmaf(r.x, f1.z, acc.z))));
+                            acc.w = fmaf(r.w, f4.w, fmaf(r.z, f3.w, fmaf(r.y, f2.w, fmaf(r.x, f1.w, acc.w))));
+                        }
                         if (k % kSB == kSB - 1) __builtin_amdgcn_sched_barrier(0);      // bounds the registers of the unrolled loop
                         if (FG && (k - P) % kFineStep == kFineStep - 1 && (k - P) / kFineStep < kFineGroups - 1) {
                             fine_consume();
