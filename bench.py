@@ -850,13 +850,16 @@ def run_flavour(dev, seed, recipe, io, steps=5, warmup=2, reuse_encoder=False, i
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     stats = {k: v for k, v in wl.group_stats().items() if k.startswith("msda_")}
-    dom = max(stats, key=lambda k: stats[k]["ms"])
+    # (the dominant KERNEL as in the headline: a group of several kernels counts with its time divided among them)
+    dom = max(stats, key=lambda k: stats[k]["ms"] / max(1, len([x for x in wl.kernels.get(k, []) if "fill" not in x])))
     g = stats[dom]
     us = g["ms"] * 1e3 / g["launches"]
     enc_b = stats.get("msda_bwd_enc_bs%d_Lq%d" % (wl.n_unsup, wl.S))
+    enc_b_us = enc_b["ms"] * 1e3 / enc_b["launches"] if enc_b else None
     res = {"ms_per_step": dt * 1e3, "images_per_s": wl.images_per_gpu / dt, "steps": steps, "dominant_kernel": dom,
            "dominant_avg_launch_us": us, "dominant_frac_hbm_peak": g["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-           "enc_bwd_avg_launch_us": enc_b["ms"] * 1e3 / enc_b["launches"] if enc_b else None,
+           "enc_bwd_avg_launch_us": enc_b_us,
+           "enc_bwd_frac_hbm_peak": enc_b["bytes"] / (enc_b_us * 1e-6) / 1e9 / HBM_PEAK_GBS if enc_b else None,
            "kernels": wl.kernels.get(dom, [])}
     del wl
     torch.cuda.empty_cache()
@@ -977,7 +980,11 @@ def main():
         value = world * ipg * args.steps / elapsed
         stats = wl.group_stats()
         msda = {k: v for k, v in stats.items() if k.startswith("msda_")}
-        dom_name = max(msda, key=lambda k: msda[k]["ms"])
+        # the dominant KERNEL: an event group that launches several kernels (the encoder backward = gather + scatter) counts with its
+        # time divided among them, so that a pair of kernels does not pass for one; the largest group's own roofline is reported next
+        # to it as `roofline_largest_group` whenever the two differ (and every group's in `roofline_groups`)
+        dom_name = max(msda, key=lambda k: msda[k]["ms"] / max(1, len([x for x in wl.kernels.get(k, []) if "fill" not in x])))
+        big_name = max(msda, key=lambda k: msda[k]["ms"])
 
         def traffic_of(group):
             """HBM-side bytes per launch of an event group, from the committed PMC passes of tools/measure_traffic.sh
@@ -1036,6 +1043,7 @@ def main():
                        "parallelism": "dp%d image-sharded, FlatDDP bucketed grad all-reduce of %d fp32 over RCCL" % (world, GRAD_ELEMS)
                        if world > 1 else "single GPU"},
             "roofline": roofline_of(dom_name),
+            "roofline_largest_group": roofline_of(big_name) if big_name != dom_name else None,
             "roofline_l1": {"bound": "l1_return", "kernel": fwd_name, "kernel_symbols": wl.kernels.get(fwd_name, []),
                             "achieved": corner_bytes / fdur / 1e9, "peak": l1_peak, "unit": "GB/s",
                             "frac": corner_bytes / fdur / 1e9 / l1_peak,

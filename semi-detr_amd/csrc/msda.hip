@@ -71,8 +71,16 @@ constexpr int kMaxLevels = 32;
                                  // + 1600: the fused prologue's location arithmetic at the start of the round that uses the loaded data, not
                                  // where the loads are issued (a round early, waiting for them): fused-prologue forward 189.8 -> 188.0 us
 #endif
+#ifndef SEMIDETR_RW_RTH
+#define SEMIDETR_RW_RTH 24       // msda_rw_d32, four levels: region rows (x 16 columns) and coarse-level margin.  24 x 16 regions hold 510 queries
+#define SEMIDETR_RW_HC 5         // (5.3 rounds of 96: better balanced than 16 x 16's 3.5) and stage 1.8 instead of 2.9 window rows per query; margin 5
+                                 // is the widest that fits then.  In the step 167.2 -> 162.2 us (16 x 16 / margin 6 -> 24 x 16 / margin 5; 32 x 16 /
+                                 // margin 4: 165.6); by spread (probe): -6 % at 1 px, -1..-4 % at 2 px, level at 2.5 - 4 px, +3 % at 5 px
+#endif
 #ifndef SEMIDETR_RW_NT5
-#define SEMIDETR_RW_NT5 1024     // ... the five-level instantiation: margin 4 is what fits either way, so the workgroup can be a full 1024 threads
+#define SEMIDETR_RW_NT5 960      // ... the five-level instantiation: margin 4 is what fits either way; 24 x 16 regions like the four-level one, and the
+                                 //     largest workgroup that fits beside their windows: 15 waves (16 x 16 / 1024 threads: 202 / 209 / 243 us at sigma 1 /
+                                 //     2 / 3 px, 24 x 16 / 960: 195 / 204 / 241, / 896: 190 / 204 / 242)
 #define SEMIDETR_RW_TUNE5 1110   //     (16 waves per CU, 128 VGPRs): ONE sample between scheduling barriers (three passes of samples per lane) and
                                  //     + 800: everything derived from the thread index rebuilt per round / region.  768 threads: 223 / 232 / 273 us
                                  //     at sigma 1 / 2 / 3 px, 1024: 208 / 225 / 255.  (Four levels at 1024 threads would have to give up margin 6
@@ -494,28 +502,30 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
         bool use_window = false;
         if (int rc = fwd_adapt_next(st, window_ok, N, L, fs, use_window)) return rc;
         if (use_window) {
-            // 16 x 16 regions, level 0 through global loads, windows of the coarse levels with the widest margin that fits beside the
+            // level 0 through global loads, windows of the coarse levels with the widest margin that fits beside the
             // octet records: one workgroup per CU either way, and the workgroup as large as its registers allow (SEMIDETR_RW_NT).
-            //   four levels: margin SIX, 123 KB of windows + 34.5 KB of records (margin 4 / 5 / 6 at sigma 2 px: 239 / 231 / 219-229 us,
-            //                at 3 px: 290 / 265 / 252 us)
-            //   five levels: margin FOUR (89 + 56 KB; margin 5 fits only a 640-thread workgroup: 251 against 234 us at 2 px), 1024
-            //                threads; patch kernel 314 / 292 / 299 us at sigma 1 / 2 / 3 px, this one 208 / 225 / 255
-            auto launch_window = [&](auto kern, size_t wlds, int threads) -> int {
+            //   four levels: 24 x 16 regions, margin FIVE, 113 KB of windows + 34.5 KB of records (16 x 16 regions at margin 4 / 5 / 6 and
+            //                sigma 2 px: 239 / 231 / 219-229 us, at 3 px: 290 / 265 / 252 us with 512 threads; SEMIDETR_RW_RTH above)
+            //   five levels: 24 x 16 regions, margin FOUR (102 + 53 KB; margin 5 fits only a 640-thread workgroup), 960 threads; patch
+            //                kernel 314 / 292 / 299 us at sigma 1 / 2 / 3 px, this one 195 / 204 / 241
+            auto launch_window = [&](auto kern, size_t wlds, int threads, int region_px) -> int {
                 if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
                 // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
                 // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
-                const int wbound = ((S * 3 / 4 + 255) / 256) * 9 / 8 + 2 * L;
+                const int wbound = ((S * 3 / 4 + region_px - 1) / region_px) * 9 / 8 + 2 * L;
                 SEMIDETR_REQUIRE((int64_t)N * wbound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
                 hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(threads), wlds, st, (const float *)nullptr,
                                    value, spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs);
                 g_last_kernels = "msda_rw_d32";
                 return semidetr::launch_status("msda_rw_d32<forward>");
             };
-            constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, 16, 16, -1, 6, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, 16, 16, -1, 4, 5>();
+            constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH, 16, -1, 4, 5>();
             static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
             if (L == 4)
-                return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, 16, 16, -1, 6, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4, SEMIDETR_RW_NT);
-            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, 16, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5);
+                return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4,
+                                     SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
+            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5,
+                                 SEMIDETR_RW_RTH * 16);
         }
         // 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges
         // included); a workgroup takes patches slot, slot + hint, ... so any hint >= 1 is correct

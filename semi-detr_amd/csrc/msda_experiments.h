@@ -62,6 +62,11 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 42: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 5120); else break;     // + 3200: window addresses by v_mad_u32_u16, FMAs with explicit op_sel
         case 43: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 1920); else break;     // the product configuration (= 734 + 1600)
         case 44: if constexpr (!GATHER) return RWT(704, 16, 16, -1, 6, 0, 1920); else break;     // 11 waves: a region's 340 queries fill 3.86 rounds of 88
+        case 45: if constexpr (!GATHER) return RWT(768, 16, 32, -1, 4, 0, 1920); else break;     // 16 x 32 regions: 680 queries = 7.1 rounds, 1.2 instead of 2.9 staged rows per query; margin 4
+        case 46: if constexpr (!GATHER) return RWT(704, 16, 32, -1, 5, 0, 1920); else break;     // ... margin 5 fits beside 88 octets' records
+        case 47: if constexpr (!GATHER) return RWT(768, 32, 16, -1, 4, 0, 1920); else break;
+        case 48: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 0, 1920); else break;     // the PRODUCT configuration: 24 x 16 regions, 510 queries = 5.3 rounds, margin 5
+        case 49: if constexpr (!GATHER) return RWT(704, 32, 16, -1, 5, 0, 1920); else break;
         case 32: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 220); else break;      // the product shape, lean
         case 33: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 240); else break;      // ... four samples between barriers again
         case 34: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 320); else break;      // the PRODUCT configuration: 12 waves per CU, margin 6
@@ -87,6 +92,8 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         if (cfg == 36) return RWT(512, 16, 16, -1, 5, 0, 320);
         if (cfg == 40) return RWT(768, 16, 16, -1, 4, 0, 1120);
         if (cfg == 41) return RWT(1024, 16, 16, -1, 4, 0, 1110);
+        if (cfg == 48) return RWT(960, 24, 16, -1, 4, 0, 1110);      // 24 x 16 regions as for four levels: 15 waves is what fits beside the windows
+        if (cfg == 49) return RWT(896, 24, 16, -1, 4, 0, 1110);
     }
     if constexpr (KL == 4) return RWT(512, 8, 16, 4, 5, 0, 40);
     else return RWT(512, 8, 16, 4, 4, 0, 40);      // five levels: the margin-5 windows do not fit 160 KB

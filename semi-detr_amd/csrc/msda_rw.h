@@ -1,10 +1,12 @@
 // Encoder self-attention with the value rows served from REGION WINDOWS in LDS (fp32, D == 32, num_point == 4):
 // forward (msda_rw_d32<..., false>) and the gather half of the backward (<..., true>: grad_sampling_loc /
 // grad_attn_weight, optionally clearing grad_value for the scatter launch that follows).  Included by msda.hip after
-// msda_fast.h / msda_region.h.  PRODUCT since round 4: the forward instantiation <512 threads, 16 x 16 regions, level 0 through
-// global loads, margin 6 on the coarse levels (159 KB of LDS), two samples between scheduling barriers> is what
+// msda_fast.h / msda_region.h.  PRODUCT since round 4: the forward instantiations <768 threads, 24 x 16 regions, level 0 through
+// global loads, margin 5 on the coarse levels> for four levels and <960 threads, 24 x 16 regions, margin 4> for five are what
 // launch_fast_forward picks while most samples stay within a few pixels of their queries (FwdStats); the other
-// configurations and the gather half are reachable from the experiments library only.
+// configurations and the gather half are reachable from the experiments library only.  The TUNE flags (scheduling barriers, level-0
+// samples in flight, which values are rebuilt per round / region instead of held in registers) are listed at msda.hip's
+// SEMIDETR_RW_TUNE; tools/rw_regs.sh compiles one configuration in seconds and prints its VGPRs and spills.
 //
 // Why.  The patch kernels (msda_fwd_d32<1,4,408>, msda_bwd_gather_d32) pull every corner row through the vector-memory
 // path: 4 x 22223 x 8 heads x 16 samples x 4 corners x 128 B = 5.8 GB per bs-4 launch at 64 B/clk/CU -- TA busy 80 %,
