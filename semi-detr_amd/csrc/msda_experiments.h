@@ -43,9 +43,9 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 1: if constexpr (!GATHER) return RWT(256, 16, 16, -1, 4, 0, 40); else return RWT(512, 8, 16, 4, 5, 0, 20);      // gather: a sample per scheduling barrier
         case 2: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 4, 0, 40); else return RWT(512, 8, 16, 4, 4, 0, 20);
         case 3: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 3, 0, 40); else return RWT(512, 8, 16, 4, 5, 0, 60);
-        case 4: if constexpr (!GATHER) return RWT(256, 8, 8, -1, 4, 0, 40); else break;
-        case 5: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 0, 40); else break;      // level 0 through global loads
-        case 6: if constexpr (!GATHER) return RWT(512, 8, 16, -1, 5, 0, 40); else break;
+        case 4: if constexpr (!GATHER) return RWT(256, 8, 8, -1, 4, 0, 40); else return RWT(768, 24, 16, -1, 5, 0, 1920);      // gather: the forward's product shape (level 0 through global loads)
+        case 5: if constexpr (!GATHER) return RWT(256, 8, 16, -1, 4, 0, 40); else return RWT(768, 24, 16, -1, 5, 0, 2720);      // level 0 through global loads; gather: everything thread-derived rebuilt
+        case 6: if constexpr (!GATHER) return RWT(512, 8, 16, -1, 5, 0, 40); else return RWT(768, 16, 16, -1, 6, 0, 1920);
         case 15: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 5, 0, 40); else break;      // the product's shape with margin 5 (134 KB of LDS)
         case 16: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 40); else break;      // margin 6: 159 KB of LDS
         case 17: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 5, 1, 40); else break;      // ... instrumented

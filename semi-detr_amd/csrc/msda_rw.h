@@ -144,7 +144,6 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     using Wn = RwWin<RTH, RTW, H0, HC, KL>;
     constexpr int P = kPT, KLP = KL * P, G = NT / 8, NPASS = (KLP + 7) / 8;
     constexpr bool FG = Wn::fine_global;                  // level 0 through global loads (forward only)
-    static_assert(!FG || !GATHER, "the gather keeps a window for every level");
     constexpr int kOctBytes = rw_oct_bytes<KL, FG>();
     constexpr int kRec0 = FG ? P : 0;                     // first sample with a window record
     constexpr int kOffAt = (KLP - kRec0) * 16, kFineAt = (KLP - kRec0) * 20, kSlotAt = kFineAt;
@@ -521,8 +520,12 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     *reinterpret_cast<uint4 *>(orec + kFineAt + k * 32) = make_uint4(
                         inside && top && lef ? base : kOob, inside && top && rig ? base + row_bytes : kOob,
                         inside && bot && lef ? base + wrow : kOob, inside && bot && rig ? base + wrow + row_bytes : kOob);
-                    *reinterpret_cast<float4 *>(orec + kFineAt + k * 32 + 16) = inside
-                        ? make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!GATHER)
+                        *reinterpret_cast<float4 *>(orec + kFineAt + k * 32 + 16) = inside
+                            ? make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    else      // the gather wants the fractions and the attention weight (zeros unless the sample counts: no 0 * NaN)
+                        *reinterpret_cast<float4 *>(orec + kFineAt + k * 32 + 16) =
+                            inside ? make_float4(lw, lh, a, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 if (k < KLP && !(FG && k < P)) {
                     *reinterpret_cast<unsigned *>(orec + kOffAt + (k - kRec0) * 4) = (first >> 4) | ((partner >> 4) << 16);
@@ -569,8 +572,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             // bottom-left, bottom-right.
 #define RW_DOT4(V_) (mygo.x * (V_).x + mygo.y * (V_).y + mygo.z * (V_).z + mygo.w * (V_).w)
 #define RW_GATHER_STEP(P_, J_, V1_, V2_, V3_, V4_, LW_, LH_, A_)                                            \
+            RW_GATHER_DOTS(P_, J_, RW_DOT4(V1_), RW_DOT4(V2_), RW_DOT4(V3_), RW_DOT4(V4_), LW_, LH_, A_)
+#define RW_GATHER_DOTS(P_, J_, D1_, D2_, D3_, D4_, LW_, LH_, A_)                                               \
             do {                                                                                               \
-                const float d1_ = RW_DOT4(V1_), d2_ = RW_DOT4(V2_), d3_ = RW_DOT4(V3_), d4_ = RW_DOT4(V4_);    \
+                const float d1_ = (D1_), d2_ = (D2_), d3_ = (D3_), d4_ = (D4_);                                \
                 const float hh_ = 1.f - (LH_), hw_ = 1.f - (LW_);                                              \
                 const float t_ = hw_ * d1_ + (LW_) * d2_, b_ = hw_ * d3_ + (LW_) * d4_;                        \
                 float pa_ = hh_ * t_ + (LH_) * b_;                                                             \
@@ -646,7 +651,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             constexpr int kFineN = (TUNE / 100) & 1 ? 1 : 2;      // level-0 samples in flight at a time (registers: 20 each)
             constexpr int kFineGroups = P / kFineN, kFineStep = (KLP - P) / kFineGroups > 0 ? (KLP - P) / kFineGroups : 1;
             float4 fv[FG ? kFineN : 1][4], fw[FG ? kFineN : 1];
+            int fine_cur = 0;                               // first level-0 sample of the group in flight
             auto fine_issue = [&](int k0) {
+                fine_cur = k0;
 #pragma unroll
                 for (int i = 0; i < kFineN; ++i) {
                     const uint4 o = *reinterpret_cast<const uint4 *>(orec + kFineAt + (k0 + i) * 32);
@@ -660,6 +667,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             auto fine_consume = [&]() {
 #pragma unroll
                 for (int i = 0; i < kFineN; ++i) {
+                    if constexpr (GATHER) {      // corners as loaded: top-left, top-right, bottom-left, bottom-right; sample fine_cur + i of pass 0
+                        RW_GATHER_STEP(0, fine_cur + i, fv[i][0], fv[i][1], fv[i][2], fv[i][3], fw[i].x, fw[i].y, fw[i].z);
+                        continue;
+                    }
                     if constexpr (((TUNE / 100) & 32) != 0) {
                         rw_fma4(acc, fw[i], fv[i][0], fv[i][1], fv[i][2], fv[i][3]);
                         continue;
@@ -708,17 +719,23 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                             acc.w = fmaf(r.w, f4.w, fmaf(r.z, f3.w, fmaf(r.y, f2.w, fmaf(r.x, f1.w, acc.w))));
                         }
                         if (k % kSB == kSB - 1) __builtin_amdgcn_sched_barrier(0);      // bounds the registers of the unrolled loop
-                        if (FG && (k - P) % kFineStep == kFineStep - 1 && (k - P) / kFineStep < kFineGroups - 1) {
-                            fine_consume();
-                            fine_issue(((k - P) / kFineStep + 1) * kFineN);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                    } else if (FG) {
+                        // (reading order -> corner order on the four DOTS, not on the sixteen row values)
+                        const bool sw = __float_as_int(r.w) != 0;
+                        const float e1 = RW_DOT4(f1), e2 = RW_DOT4(f2), e3 = RW_DOT4(f3), e4 = RW_DOT4(f4);
+                        RW_GATHER_DOTS(k >> 3, k & 7, sw ? e2 : e1, sw ? e1 : e2, sw ? e4 : e3, sw ? e3 : e4, r.x, r.y, r.z);
+                        if (k % kSB == kSB - 1) __builtin_amdgcn_sched_barrier(0);
                     } else {
                         const bool sw = __float_as_int(r.w) != 0;
                         const float4 vtl = sw ? f2 : f1, vtr = sw ? f1 : f2, vbl = sw ? f4 : f3, vbr = sw ? f3 : f4;
                         RW_GATHER_STEP(k >> 3, k & 7, vtl, vtr, vbl, vbr, r.x, r.y, r.z);
                         // keep the scheduler from hoisting the whole unrolled loop's LDS reads (256 VGPRs and spills otherwise)
                         if (k % (kSB / 2 > 0 ? kSB / 2 : 1) == (kSB / 2 > 0 ? kSB / 2 : 1) - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (FG && (k - P) % kFineStep == kFineStep - 1 && (k - P) / kFineStep < kFineGroups - 1) {
+                        fine_consume();      // hand-over point of the level-0 samples: the group in flight is used, the next one issued
+                        fine_issue(((k - P) / kFineStep + 1) * kFineN);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -809,6 +826,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 }
             }
 #undef RW_GATHER_STEP
+#undef RW_GATHER_DOTS
 #undef RW_DOT4
             lap(9);                                // 9: results
         }
