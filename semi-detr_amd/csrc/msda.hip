@@ -55,6 +55,9 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_SCATTER_Q 176     // (a region of an 800 x 1333 pyramid has at most 171 queries: one pass; more take several)
 #define SEMIDETR_SCATTER_WPE 6
 #endif
+#ifndef SEMIDETR_SCATTER_WU
+#define SEMIDETR_SCATTER_WU 8      // entries per stream and trip of the row walk (+ 1000: paired corners, msda_region.h)
+#endif
 #ifndef SEMIDETR_SCATTER_NT
 #define SEMIDETR_SCATTER_NT 512    // (704 threads = one sample per thread, no half-empty second sample slot, two workgroups per CU:
 #endif                             //  encoder backward 726 against 678 us at bs 4 -- the third workgroup is worth more)
@@ -585,7 +588,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
         if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
-        auto kern = &msda_bwd_scatter_d32_reg<IO, SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 8, 16, 24, 32, 0, SEMIDETR_SCATTER_WPE, 8>;
+        auto kern = &msda_bwd_scatter_d32_reg<IO, SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 8, 16, 24, 32, 0, SEMIDETR_SCATTER_WPE, SEMIDETR_SCATTER_WU>;
         const size_t rlds = reg_lds_bytes<SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 24, 32>();
         if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
         const int rbound = (S + 127) / 128 * 5 / 4 + 4 * L;

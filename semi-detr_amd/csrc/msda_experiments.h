@@ -638,6 +638,29 @@ int exp_launch_fast_backward(hipStream_t st, const float *grad_out, const float 
                 const size_t rlds = reg_lds_bytes<512, 208, 24, 32>();
                 hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S,
                                    M, L, rbound, grad_value);
+            } else if (g_bwd_variant == 6988 || g_bwd_variant == 6989) {            // timing aids: no second-row flushes / no misses
+                const size_t rlds = reg_lds_bytes<512, 176, 24, 32>();
+                if (g_bwd_variant == 6988)
+                    hipLaunchKernelGGL((msda_bwd_scatter_d32_reg_pair_aid<IO, 4>), dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, rbound, grad_value);
+                else
+                    hipLaunchKernelGGL((msda_bwd_scatter_d32_reg_pair_aid<IO, 8>), dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, rbound, grad_value);
+            } else if (g_bwd_variant == 6986 || g_bwd_variant == 6987) {            // paired corners without / with the row atomics
+                const size_t rlds = reg_lds_bytes<512, 176, 24, 32>();
+                if (g_bwd_variant == 6986)
+                    hipLaunchKernelGGL((msda_bwd_scatter_d32_reg_pair_aid<IO, 2>), dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, rbound, grad_value);
+                else
+                    hipLaunchKernelGGL((msda_bwd_scatter_d32_reg_pair_aid<IO, 0>), dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, rbound, grad_value);
+            } else if (g_bwd_variant == 6960 || g_bwd_variant == 6961) {            // instrumented: the product shape / with paired corners
+                const size_t rlds = reg_lds_bytes<512, 176, 24, 32>();
+                if (g_bwd_variant == 6960) {
+                    auto kern = &msda_bwd_scatter_d32_reg<IO, 512, 176, 8, 16, 24, 32, 1, 6, 8>;
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, rbound, grad_value);
+                } else {
+                    auto kern = &msda_bwd_scatter_d32_reg<IO, 512, 176, 8, 16, 24, 32, 1, 6, 1004>;
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(512), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L, rbound, grad_value);
+                }
             } else if (g_bwd_variant == 691) LAUNCH_REG(512, 208, 16, 8, 32, 24);   // tuning variants
             else if (g_bwd_variant == 692) LAUNCH_REG(256, 112, 8, 8, 24, 24);
             else if (g_bwd_variant == 693) LAUNCH_REG(512, 112, 8, 8, 24, 24);

@@ -38,6 +38,13 @@ __device__ __forceinline__ void reg_scatter_body(
     const float *__restrict__ value = nullptr)
 {
     constexpr int kWR = WH * WW, kNE = kRegQ * kPT * 4, SPT = (kRegQ * kPT + NT - 1) / NT, KC = (kWR + NT - 1) / NT;
+    // WU >= 1000: PAIRED corners.  The left and the right corner of a sample's top (bottom) edge land on NEIGHBOURING window rows, so
+    // one 16-byte entry {w_left, w_right, word} bucketed by the LEFT row serves both: half the entries to count, fill and walk; the
+    // walk keeps the sums of rows r and r + 1 and hands the second one on when the next run is row r + 1 (flag in the run's last entry),
+    // so rows are flushed as often as before.  A corner whose partner is missing (level border) or outside the window goes to the miss
+    // list on its own, as out-of-window corners always did.
+    constexpr bool kPair = WU >= 1000;
+    static_assert(!kPair || FUSE == 0, "the fused-backward experiment indexes one entry per corner");
     static_assert(kRegQ <= 512 && kWR <= (1 << 14), "entry packing: 9 bits query slot (x 128), 14 bits window row, sign bit = last");
     float2 *entries = reinterpret_cast<float2 *>(smem);   // [kNE + 8] front: bucketed {weight, last << 31 | window row << 16 | slot << 7};
                                                           // back: misses {weight, slot << 23 | pixel index}
@@ -261,8 +268,15 @@ __device__ __forceinline__ void reg_scatter_body(
                     for (int cidx = 0; cidx < 4; ++cidx) {
                         const int wr = s_wi[sp] + (cidx & 1) + (cidx >> 1) * WW;
                         rank[sp][cidx] = -1;
+                        // paired mode: both corners of the edge lie inside the window and at least one of them exists -> ONE count, on
+                        // the left row (a corner outside the level or masked enters with weight zero; its row is never flushed)
+                        const bool paired = kPair && (s_fl[sp] & (0x30 << (cidx & 2))) == (0x30 << (cidx & 2)) && (s_fl[sp] & (3 << (cidx & 2)));
+                        if (paired) {
+                            if (!(cidx & 1)) rank[sp][cidx] = atomicAdd(&cnt[wr], 1);
+                            continue;
+                        }
                         if (!(s_fl[sp] & (1 << cidx))) continue;          // corner outside the level (or masked)
-                        if (s_fl[sp] & (16 << cidx)) {
+                        if (!kPair && (s_fl[sp] & (16 << cidx))) {
                             rank[sp][cidx] = atomicAdd(&cnt[wr], 1);
                         } else {                          // pixel index (< 2^23, checked by the launcher) + slot
                             const int at = kNE - 1 - atomicAdd(&stats[1], 1);
@@ -312,6 +326,19 @@ __device__ __forceinline__ void reg_scatter_body(
 #pragma unroll
                     for (int cidx = 0; cidx < 4; ++cidx) {
                         const int wr = s_wi[sp] + (cidx & 1) + (cidx >> 1) * WW;
+                        if constexpr (kPair) {
+                            // {w_left, w_right, last << 31 | next row not empty << 30 | left row << 16 | slot << 7}: the walk hands the
+                            // right row's sum on to the run that follows when that run IS the right row
+                            if (!(cidx & 1) && (s_fl[sp] & (0x30 << cidx)) == (0x30 << cidx) && (s_fl[sp] & (3 << cidx))) {
+                                const int at = start[wr] + rank[sp][cidx];
+                                const bool last = rank[sp][cidx] == cnt[wr] - 1;
+                                const bool next_there = wr + 1 < kWR && cnt[wr + 1] > 0;
+                                reinterpret_cast<float4 *>(entries)[at] = make_float4(
+                                    (s_fl[sp] & (1 << cidx)) ? cwv[cidx] : 0.f, (s_fl[sp] & (2 << cidx)) ? cwv[cidx + 1] : 0.f,
+                                    __int_as_float((last ? (int)0x80000000 : 0) | (last && next_there ? 0x40000000 : 0) | (wr << 16) | (i << 7)), 0.f);
+                            }
+                            continue;
+                        }
                         if ((s_fl[sp] & (17 << cidx)) == (17 << cidx)) {      // exists and inside the window
                             const int at = start[wr] + rank[sp][cidx];
                             entries[at] = make_float2(
@@ -416,7 +443,7 @@ __device__ __forceinline__ void reg_scatter_body(
                     // WU >= 100: shares start on even entries (16-byte aligned: two entries per ds_read_b128, which moves twice
                     // the bytes per LDS cycle of the ds_read2_b64 the compiler picks for single entries) and the entries of batch
                     // i + 1 are requested before batch i is processed
-                    constexpr bool kPipe = WU >= 100;
+                    constexpr bool kPipe = WU >= 100 && WU < 1000;
                     constexpr int WB = WU % 100;
                     const int lo = kPipe ? ((int)((int64_t)total * sid / kStreams) & ~1) : (int)((int64_t)total * sid / kStreams);
                     const int hi = kPipe ? (sid + 1 == kStreams ? total : ((int)((int64_t)total * (sid + 1) / kStreams) & ~1))
@@ -444,7 +471,70 @@ __device__ __forceinline__ void reg_scatter_body(
                         }
                     };
                     int e = lo;
-                    if constexpr (kPipe) {
+                    if constexpr (kPair) {
+                        // paired entries: sums of rows cur (accv) and cur + 1 (accr)
+                        const float4 *e4 = reinterpret_cast<const float4 *>(entries);
+                        float2 accr = make_float2(0.f, 0.f);
+                        bool open_r = false;             // accr holds contributions (row cur + 1 is then a valid pixel)
+                        auto flush2 = [&](int rowi, const float2 &a) {
+                            if (DBG && l16 == 0) SEMIDETR_DBG_ADD(12 + (l < 4 ? l : 3), 1);      // flushed rows by sampling level
+                            // a window row outside the level only ever collected zero weights (or NaN from a non-finite grad_out): skip it
+                            if ((unsigned)(y0 + rowi / WW) >= (unsigned)H || (unsigned)(x0 + rowi % WW) >= (unsigned)W) return;
+                            float *pr = gvs + (int64_t)(base_pix + (rowi / WW) * W + rowi % WW) * rs;
+                            if ((AID & 2) && a.x != 1.2345e30f) return;
+                            fp_atomic_add(pr, a.x);
+                            fp_atomic_add(pr + 16, a.y);
+                        };
+                        auto pstep = [&](const float4 &en, const float2 &gq) {
+                            const int pk = __float_as_int(en.z);
+                            accv.x += en.x * gq.x;
+                            accv.y += en.x * gq.y;
+                            accr.x += en.y * gq.x;
+                            accr.y += en.y * gq.y;
+                            open_r = true;
+                            cur = (pk >> 16) & 0x3fff;
+                            if (pk < 0) {                // last entry of row cur's run
+                                flush2(cur, accv);
+                                if (pk & 0x40000000) {   // the next run is row cur + 1: its sum so far moves over
+                                    accv = accr;
+                                    cur = cur + 1;
+                                } else {
+                                    if (!(AID & 4)) flush2(cur + 1, accr);
+                                    accv = make_float2(0.f, 0.f);
+                                    cur = -1;
+                                }
+                                accr = make_float2(0.f, 0.f);
+                                open_r = false;
+                            }
+                        };
+                        constexpr int WB = WU % 100;
+                        for (; e + WB <= hi; e += WB) {
+                            float4 en[WB];
+                            float2 gq[WB];
+#pragma unroll
+                            for (int u = 0; u < WB; ++u) en[u] = e4[e + u];
+#pragma unroll
+                            for (int u = 0; u < WB; ++u) gq[u] = gq_of(en[u].z);
+#pragma unroll
+                            for (int u = 0; u < WB; ++u) pstep(en[u], gq[u]);
+                        }
+                        if (e < hi) {       // tail of < WB entries
+                            float4 en[WB];
+                            float2 gq[WB];
+#pragma unroll
+                            for (int u = 0; u < WB; ++u) en[u] = e4[min(e + u, hi - 1)];
+#pragma unroll
+                            for (int u = 0; u < WB; ++u) gq[u] = gq_of(en[u].z);
+#pragma unroll
+                            for (int u = 0; u < WB; ++u)
+                                if (e + u < hi) pstep(en[u], gq[u]);
+                        }
+                        if (cur >= 0) {
+                            flush2(cur, accv);
+                            if (open_r && !(AID & 4)) flush2(cur + 1, accr);
+                            cur = -1;
+                        }
+                    } else if constexpr (kPipe) {
                         const float4 *e4 = reinterpret_cast<const float4 *>(entries);
                         float4 ea[WB / 2];
 #pragma unroll
@@ -504,7 +594,7 @@ __device__ __forceinline__ void reg_scatter_body(
                     if (cur >= 0) flush(cur);
                     // ---- misses: one row update per (sample, corner), as the plain kernel does
                     const int nmiss = stats[1];
-                    for (int mi = sid; mi < nmiss; mi += kStreams) {
+                    for (int mi = sid; mi < ((AID & 8) ? 0 : nmiss); mi += kStreams) {
                         const float2 en = entries[kNE - 1 - mi];
                         const int pk = __float_as_int(en.y);
                         const float2 g2 = gt2[((unsigned)pk >> 23) * 16 + l16];
@@ -576,6 +666,15 @@ __global__ __launch_bounds__(NT, WPE) void msda_bwd_scatter_d32_reg(
 }
 
 #if SEMIDETR_EXPERIMENTS
+// timing aids (backward variants 6986 / 6987, the first one's results wrong): the PAIRED-corner scatter without / with its row atomics
+template <typename IO, int AID>
+__global__ __launch_bounds__(512, 6) void msda_bwd_scatter_d32_reg_pair_aid(
+    const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
+    const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
+{
+    extern __shared__ float4 smem[];
+    reg_scatter_body<IO, 512, 176, 8, 16, 24, 32, 0, 1004, 0, AID>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, regions_bound, gvalue);
+}
 // timing aid (backward variant 6985, results wrong): the region scatter WITHOUT its row atomics -- what the compute side alone costs
 template <typename IO>
 __global__ __launch_bounds__(512, 4) void msda_bwd_scatter_d32_reg_noatomics(
