@@ -133,8 +133,16 @@ __device__ __forceinline__ void rw_fma4(float4 &acc, const float4 &w, const floa
 
 // DBG (tuning builds only): 1 = per-phase cycle counts of wave 0 into g_dest_dbg, 2 = windows not staged (results
 // wrong, timing aid), 3 = compute loop skipped (results wrong, timing aid)
-// TUNE = 10 * (compute-loop steps between scheduling barriers) + (out-of-window samples per octet whose loads are issued
-// ahead of the compute loop)
+// TUNE = 100 * flags + 10 * (compute-loop samples between scheduling barriers) + (out-of-window samples per octet whose loads are
+//        issued ahead of the compute loop; 0 whenever level 0 has no window).  Flags (every combination gives the same results):
+//          1  one level-0 sample's corner loads in flight instead of two (-33 VGPRs)
+//          2  "lean": the per-lane level constants are re-selected where they are used, the staging coordinates rebuilt per region
+//          4  one instead of two out-of-window samples per trip of the fall-back loop
+//          8  everything else derived from the thread index (octet / window addresses, per-level lane values, division
+//             reciprocals of the region grid) rebuilt per round / region through an empty asm: what fits 1024 threads into 128 VGPRs
+//         16  the prefetched sampling data stay as loaded; the fused prologue's location arithmetic runs in the consuming round
+//         32  window addresses by v_mad_u32_u16, packed FMAs with explicit op_sel (measured level; experiments)
+//        Product: 1920 = 16 + 2 + 1, two samples per barrier (four levels); 1110 = 8 + 2 + 1, one sample per barrier (five levels).
 template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GATHER, int DBG = 0, int TUNE = 42>
 __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(      // 256-thread workgroups: two per CU
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,

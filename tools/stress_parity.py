@@ -25,8 +25,11 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs (to find a crashing one)")
     ap.add_argument("--variant", type=int, nargs=2, default=[0, 0], help="forced (fwd, bwd) kernel variants; cases a forced "
                     "variant does not apply to are skipped")
+    ap.add_argument("--policy", default="adaptive", choices=["adaptive", "patch", "window"],
+                    help="encoder forward kernel (semidetr_msda_set_forward_policy); \"window\" sends every eligible case through msda_rw_d32")
     a = ap.parse_args()
     import semi_detr_amd  # noqa: F401  (installs the module below)
+    semi_detr_amd._lib.set_forward_policy(a.policy)
     import MultiScaleDeformableAttention as MSDA
     semi_detr_amd._lib.set_variant(*a.variant)
     rng = np.random.default_rng(a.seed)
