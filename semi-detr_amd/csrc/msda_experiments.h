@@ -15,14 +15,14 @@ int launch_rw(hipStream_t st, const float *grad_out, const float *value, const i
               const int64_t *level_start, const IO &io, int N, int S, int M, float *out, float4 *zero, int64_t zero_n4)
 {
     auto kern = &msda_rw_d32<IO, NT, RTH, RTW, H0, HC, KL, GATHER, DBG, TUNE>;
-    if (int rc = allow_big_lds(kern, rw_lds_bytes<NT, RTH, RTW, H0, HC, KL>(), "msda region-window kernel")) return rc;
+    if (int rc = allow_big_lds(kern, rw_lds_bytes<NT, RTH, RTW, H0, HC, KL, TUNE>(), "msda region-window kernel")) return rc;
     // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
     // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
     const int rpx = RTH * RTW;
     const int bound = ((S * 3 / 4 + rpx - 1) / rpx) * 9 / 8 + 2 * KL;
     const int64_t grid = (int64_t)N * bound * M;
     SEMIDETR_REQUIRE(grid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda: grid too large");
-    constexpr size_t lds = rw_lds_bytes<NT, RTH, RTW, H0, HC, KL>();
+    constexpr size_t lds = rw_lds_bytes<NT, RTH, RTW, H0, HC, KL, TUNE>();
     static_assert(lds <= 160 * 1024, "region-window configuration does not fit the LDS");
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, grad_out, value, spatial_shapes, level_start, io, S, M,
                        bound, out, zero, zero_n4, FwdStats{nullptr, nullptr, nullptr, nullptr});
@@ -67,6 +67,11 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 47: if constexpr (!GATHER) return RWT(768, 32, 16, -1, 4, 0, 1920); else break;
         case 48: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 0, 1920); else break;     // the PRODUCT configuration: 24 x 16 regions, 510 queries = 5.3 rounds, margin 5
         case 49: if constexpr (!GATHER) return RWT(704, 32, 16, -1, 5, 0, 1920); else break;
+        case 51: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 0, 1921); else break;     // + ONE out-of-window sample per octet pre-issued before the LDS loop
+        case 52: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 0, 2721); else break;
+        case 53: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 0, 2722); else break;
+        case 54: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 1, 2721); else break;     // ... instrumented
+        case 50: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 1, 1920); else break;     // the product configuration, instrumented (tools/r03_rw_dbg.py 750)
         case 32: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 220); else break;      // the product shape, lean
         case 33: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 240); else break;      // ... four samples between barriers again
         case 34: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 320); else break;      // the PRODUCT configuration: 12 waves per CU, margin 6

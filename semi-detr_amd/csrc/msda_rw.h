@@ -72,19 +72,20 @@ struct RwWin {
     static constexpr int total = zrow + zrows;
 };
 
-template <int KL, bool FG = false>
+template <int KL, bool FG = false, bool PRE = false>
 constexpr int rw_oct_bytes()      // per octet: {float4 record} and {two 16-bit window offsets} per windowed sample | two 32-byte slots (+ bank spread)
 {
     // level 0 without a window (FG): its samples have no window record; their {corner offsets, weights} records (32 bytes each) are
-    // dead by the time the out-of-window loop needs its two slots, so the slots lie on top of them
-    constexpr int raw = FG ? (KL - 1) * kPT * 20 + kPT * 32 : KL * kPT * 20 + 64;
+    // dead by the time the out-of-window loop needs its two slots, so the slots lie on top of them -- unless out-of-window samples
+    // are pre-issued (PRE: TUNE % 10 > 0), whose slots are written while those records are still live
+    constexpr int raw = FG ? (KL - 1) * kPT * 20 + kPT * 32 + (PRE ? 64 : 0) : KL * kPT * 20 + 64;
     return raw + (raw % 128 == 0 ? 16 : 0);      // octet pitch: A, B, C, D on distinct banks
 }
 
-template <int NT, int RTH, int RTW, int H0, int HC, int KL>
+template <int NT, int RTH, int RTW, int H0, int HC, int KL, int TUNE = 0>
 constexpr size_t rw_lds_bytes()
 {
-    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)(NT / 8) * rw_oct_bytes<KL, (H0 < 0)>();
+    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)(NT / 8) * rw_oct_bytes<KL, (H0 < 0), (TUNE % 10 > 0)>();
 }
 
 // smallest q in [0, nq] with ((2 q + 1) * nb) / (2 * nq) >= bound  (the first pixel of a level with nq rows whose centre
@@ -134,7 +135,8 @@ __device__ __forceinline__ void rw_fma4(float4 &acc, const float4 &w, const floa
 // DBG (tuning builds only): 1 = per-phase cycle counts of wave 0 into g_dest_dbg, 2 = windows not staged (results
 // wrong, timing aid), 3 = compute loop skipped (results wrong, timing aid)
 // TUNE = 100 * flags + 10 * (compute-loop samples between scheduling barriers) + (out-of-window samples per octet whose loads are
-//        issued ahead of the compute loop; 0 whenever level 0 has no window).  Flags (every combination gives the same results):
+//        issued ahead of the compute loop: with level 0 through global loads their slots need 64 more bytes per octet; measured level,
+//        0 in the product).  Flags (every combination gives the same results):
 //          1  one level-0 sample's corner loads in flight instead of two (-33 VGPRs)
 //          2  "lean": the per-lane level constants are re-selected where they are used, the staging coordinates rebuilt per region
 //          4  one instead of two out-of-window samples per trip of the fall-back loop
@@ -152,10 +154,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     using Wn = RwWin<RTH, RTW, H0, HC, KL>;
     constexpr int P = kPT, KLP = KL * P, G = NT / 8, NPASS = (KLP + 7) / 8;
     constexpr bool FG = Wn::fine_global;                  // level 0 through global loads (forward only)
-    constexpr int kOctBytes = rw_oct_bytes<KL, FG>();
+    constexpr int kOctBytes = rw_oct_bytes<KL, FG, (TUNE % 10 > 0)>();
     constexpr int kRec0 = FG ? P : 0;                     // first sample with a window record
-    constexpr int kOffAt = (KLP - kRec0) * 16, kFineAt = (KLP - kRec0) * 20, kSlotAt = kFineAt;
-    static_assert(!FG || TUNE % 10 == 0, "without a level-0 window the slots of pre-issued out-of-window samples would overwrite live records");
+    constexpr int kOffAt = (KLP - kRec0) * 16, kFineAt = (KLP - kRec0) * 20, kSlotAt = (FG && TUNE % 10 > 0) ? kFineAt + P * 32 : kFineAt;
     static_assert(Wn::total * 128 <= (1 << 20), "window offsets are kept in 16 bits, in units of 16 bytes");
     constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
     static_assert(P == 4 && KLP <= 32, "lane j of an octet owns samples j, j + 8, ...");
