@@ -71,6 +71,9 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 52: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 0, 2721); else break;
         case 53: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 0, 2722); else break;
         case 54: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 1, 2721); else break;     // ... instrumented
+        case 55: if constexpr (!GATHER) return RWT(768, 22, 16, -1, 5, 0, 1920); else break;     // region heights by how evenly their queries fill rounds of 96: 22 rows = 4.87
+        case 56: if constexpr (!GATHER) return RWT(768, 25, 16, -1, 5, 0, 1920); else break;     // 25 rows = 5.53 (and four region rows exactly on a 100-row level)
+        case 57: if constexpr (!GATHER) return RWT(768, 20, 16, -1, 5, 0, 1920); else break;     // 20 rows = 4.43
         case 50: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 1, 1920); else break;     // the product configuration, instrumented (tools/r03_rw_dbg.py 750)
         case 32: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 220); else break;      // the product shape, lean
         case 33: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 240); else break;      // ... four samples between barriers again
