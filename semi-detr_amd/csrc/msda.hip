@@ -51,6 +51,10 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_GATHER_WPE 5
 #define SEMIDETR_GATHER_KB 2
 #endif
+#ifndef SEMIDETR_GATHER5_WPE     // ... the five-level (20-sample) instantiation
+#define SEMIDETR_GATHER5_WPE 4      // (5 / 2 as for four levels: COCO-Full encoder backward 9.77 -> 9.69 ms per step, but the fused-prologue
+#define SEMIDETR_GATHER5_KB 4       //  instantiation spills 4 registers there -- left as it is)
+#endif
 #ifndef SEMIDETR_SCATTER_Q       // region scatter: queries per pass (LDS) and waves per SIMD
 #define SEMIDETR_SCATTER_Q 176     // (a region of an 800 x 1333 pyramid has at most 171 queries: one pass; more take several)
 #define SEMIDETR_SCATTER_WPE 6
@@ -582,7 +586,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, SEMIDETR_GATHER_WPE, SEMIDETR_GATHER_KB>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound, zero, (int64_t)(fill / 16));
         else if (L * P == 20)        // five levels (COCO-Full recipe)
-            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 20, 408>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
+            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 20, 408, SEMIDETR_GATHER5_WPE, SEMIDETR_GATHER5_KB>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound, zero, (int64_t)(fill / 16));
         else
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
