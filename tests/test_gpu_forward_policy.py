@@ -160,3 +160,35 @@ def test_adaptive_policy_follows_the_sample_spread():
     st2 = sda._lib.forward_policy_state()
     assert st2["mode"] == 0 and st2["far_fraction"] > 0.70, st2
     assert k_far[0] == "msda_rw_d32" and k_far[-1] == "msda_fwd_d32<1, 4, 408", k_far
+
+
+@pytest.mark.parametrize("policy", ["window", "adaptive"])
+def test_forward_inside_a_stream_capture(policy):
+    """The encoder forward captured into a HIP graph and replayed: the dispatcher must not allocate, copy or synchronise while
+    the stream is capturing (include/semidetr_hip.h: "launches inside a stream capture keep the kernel of the moment and count
+    nothing"), and the replayed launch gives the oracle's result for new contents of the same buffers."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd as sda
+    shapes = [(40, 54), (20, 27), (10, 14), (5, 7)]
+    value, shp, loc, attn = _case(shapes, 2, "near", 31)
+    tsh = _t(shp)
+    tls = _starts(tsh)
+    tv, tl, ta = _t(value), _t(loc), _t(attn)
+    sda._lib.set_forward_policy(policy)
+    for _ in range(3):                                     # warm-up outside the capture (first-use allocations, LDS attribute)
+        MSDA.ms_deform_attn_forward(tv, tsh, tls, tl, ta, 64)
+        torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            out = MSDA.ms_deform_attn_forward(tv, tsh, tls, tl, ta, 64)
+    torch.cuda.current_stream().wait_stream(s)
+    before = sda._lib.forward_policy_state()["updates"]      # (the capturing dispatch may still have picked up the warm-up launches' counts)
+    value2, _, loc2, attn2 = _case(shapes, 2, "near", 32)
+    tv.copy_(_t(value2)); tl.copy_(_t(loc2)); ta.copy_(_t(attn2))
+    g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.msda_forward(value2, shp, loc2, attn2), rtol=0, atol=2e-6)
+    assert sda._lib.forward_policy_state()["updates"] == before      # the replayed launch counted nothing
