@@ -80,6 +80,8 @@ constexpr int kMaxLevels = 32;
 #endif
 #ifndef SEMIDETR_RW_RTH
 #define SEMIDETR_RW_RTH 24       // msda_rw_d32, four levels: region rows (x 16 columns) and coarse-level margin.  24 x 16 regions hold 510 queries
+#endif
+#ifndef SEMIDETR_RW_HC
 #define SEMIDETR_RW_HC 5         // (5.3 rounds of 96: better balanced than 16 x 16's 3.5) and stage 1.8 instead of 2.9 window rows per query; margin 5
                                  // is the widest that fits then.  In the step 167.2 -> 162.2 us (16 x 16 / margin 6 -> 24 x 16 / margin 5; 32 x 16 /
                                  // margin 4: 165.6); by spread (probe): -6 % at 1 px, -1..-4 % at 2 px, level at 2.5 - 4 px, +3 % at 5 px
