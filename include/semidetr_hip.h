@@ -127,7 +127,7 @@ int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const 
  * no padding mask).  The reference has one kernel for everything (ms_deform_im2col_cuda.cuh:237-299); here two
  * produce the same results at different speeds depending on how far the learned offsets reach:
  *   patch kernel   -- 4 x 8 query patches, every corner row through the vector-memory path; insensitive to the offsets
- *   window kernel  -- 24 x 16 regions, the coarse levels' corner rows from LDS windows +- 5 px (five levels: +- 4 px) around
+ *   window kernel  -- regions of up to 25 x 16 pixels, the coarse levels' corner rows from LDS windows +- 5 px (five levels: +- 4 px) around
  *                     the region; 10-25 % faster while most samples stay inside, level with the patch kernel when ~70 % of
  *                     them are more than 4 px away (sigma ~5.5 px), slower beyond
  * policy 0 (default, adaptive): both kernels count, in a few workgroups, the share of samples further than 4 px from their

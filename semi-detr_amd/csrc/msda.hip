@@ -79,13 +79,18 @@ constexpr int kMaxLevels = 32;
                                  // where the loads are issued (a round early, waiting for them): fused-prologue forward 189.8 -> 188.0 us
 #endif
 #ifndef SEMIDETR_RW_RTH
-#define SEMIDETR_RW_RTH 24       // msda_rw_d32, four levels: region rows (x 16 columns) and coarse-level margin.  24 x 16 regions hold 510 queries
+#define SEMIDETR_RW_RTH 25       // msda_rw_d32, four levels: LARGEST region height (x 16 columns; the grid is tiled evenly, msda_rw.h) and coarse-level
+                                 // margin.  24 x 16 regions hold 510 queries
 #endif
 #ifndef SEMIDETR_RW_HC
 #define SEMIDETR_RW_HC 5         // (5.3 rounds of 96: better balanced than 16 x 16's 3.5) and stage 1.8 instead of 2.9 window rows per query; margin 5
                                  // is the widest that fits then.  In the step 167.2 -> 162.2 us (16 x 16 / margin 6 -> 24 x 16 / margin 5; 32 x 16 /
                                  // margin 4: 165.6); by spread (probe): -6 % at 1 px, -1..-4 % at 2 px, level at 2.5 - 4 px, +3 % at 5 px
 #endif
+#ifndef SEMIDETR_RW_RTH5
+#define SEMIDETR_RW_RTH5 24      // ... five levels.  With the evenly tiled grid (a 100-row level = 4 x 25 or 5 x 20 rows instead of 4 x 24 + 4), in
+#endif                           // the step: four levels 25 / 24 rows 162.2 / 166.7 us (fused prologue 172.7 / 179.1; uneven 24: 162.0 / 176.5),
+                                 // five levels 254 / 249 us (uneven 24: 257) -- what decides is how evenly a region's queries fill its rounds
 #ifndef SEMIDETR_RW_NT5
 #define SEMIDETR_RW_NT5 960      // ... the five-level instantiation: margin 4 is what fits either way; 24 x 16 regions like the four-level one, and the
                                  //     largest workgroup that fits beside their windows: 15 waves (16 x 16 / 1024 threads: 202 / 209 / 243 us at sigma 1 /
@@ -528,13 +533,13 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
                 g_last_kernels = "msda_rw_d32";
                 return semidetr::launch_status("msda_rw_d32<forward>");
             };
-            constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH, 16, -1, 4, 5>();
+            constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5>();
             static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
             if (L == 4)
                 return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4,
                                      SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
-            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5,
-                                 SEMIDETR_RW_RTH * 16);
+            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5,
+                                 SEMIDETR_RW_RTH5 * 16);
         }
         // 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges
         // included); a workgroup takes patches slot, slot + hint, ... so any hint >= 1 is correct

@@ -1,8 +1,8 @@
 // Encoder self-attention with the value rows served from REGION WINDOWS in LDS (fp32, D == 32, num_point == 4):
 // forward (msda_rw_d32<..., false>) and the gather half of the backward (<..., true>: grad_sampling_loc /
 // grad_attn_weight, optionally clearing grad_value for the scatter launch that follows).  Included by msda.hip after
-// msda_fast.h / msda_region.h.  PRODUCT since round 4: the forward instantiations <768 threads, 24 x 16 regions, level 0 through
-// global loads, margin 5 on the coarse levels> for four levels and <960 threads, 24 x 16 regions, margin 4> for five are what
+// msda_fast.h / msda_region.h.  PRODUCT since round 4: the forward instantiations <768 threads, regions of up to 25 x 16 pixels, level 0
+// through global loads, margin 5 on the coarse levels> for four levels and <960 threads, up to 24 x 16, margin 4> for five are what
 // launch_fast_forward picks while most samples stay within a few pixels of their queries (FwdStats); the other
 // configurations and the gather half are reachable from the experiments library only.  The TUNE flags (scheduling barriers, level-0
 // samples in flight, which values are rebuilt per round / region instead of held in registers) are listed at msda.hip's
@@ -265,8 +265,12 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         int Hb_r = Hb_k, Wb_r = Wb_k, nrx_r = nrx_k;      // TUNE + 800: ... and the reciprocals of the divisions by these
         if ((TUNE / 100) & 8) asm volatile("" : "+s"(Hb_r), "+s"(Wb_r), "+s"(nrx_r));
         const int Hb = Hb_r, Wb = Wb_r, nrx = nrx_r;
-        const int y0b = (reg / nrx) * RTH, x0b = (reg % nrx) * RTW;
-        const int y1b = min(y0b + RTH, Hb), x1b = min(x0b + RTW, Wb);
+        // BALANCED tiling: the grid's ceil(H / RTH) x ceil(W / RTW) regions share the rows / columns evenly (heights differ by at most
+        // one row, none exceeds RTH: what the windows are sized for) instead of leaving a sliver at the bottom and right edges -- a
+        // 100-row level is 4 x 25 or 5 x 20 rows, not 4 x 24 + 4
+        const int nry_b = (Hb + RTH - 1) / RTH, ry_b = reg / nrx, rx_b = reg - ry_b * nrx;
+        const int y0b = (ry_b * Hb) / nry_b, y1b = ((ry_b + 1) * Hb) / nry_b;
+        const int x0b = (rx_b * Wb) / nrx, x1b = ((rx_b + 1) * Wb) / nrx;
         // TUNE + 800: the per-level lane values are rebuilt per region from their wave-uniform copies (one select per level)
         // instead of living in six registers from the kernel's first instruction on
         int lane_t = tid;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         int r_ylo = 0, r_xlo = 0, r_w = 1, r_cnt = 0;
         float r_invw = 1.f;
         // window origins: where the region centre maps to on each level, minus half the window
-        const float pcy = (y0b + 0.5f * RTH) / (float)Hb, pcx = (x0b + 0.5f * RTW) / (float)Wb;
+        const float pcy = 0.5f * (float)(y0b + y1b) / (float)Hb, pcx = 0.5f * (float)(x0b + x1b) / (float)Wb;      // centre of the region as it is
         const int r_wy0 = (int)floorf(pcy * (float)r_H - 0.5f) - r_wh / 2 + 1;
         const int r_wx0 = (int)floorf(pcx * (float)r_W - 0.5f) - r_ww / 2 + 1;
         if (lane < KL) {

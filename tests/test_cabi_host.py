@@ -55,8 +55,8 @@ def test_product_code_object_holds_only_reachable_msda_kernels():
                    "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "stream_kernel", "msda_bwd_own_merged",
                    "msda_fwd_d32_ws", "msda_bwd_lvl_mergedI", "msda_bwd_enc_fused_d32"):
         assert banned not in syms, banned
-    rw = sorted(n for n in names if "msda_rw_d32" in n)       # LocAttnIO + RawIO of <768, 24, 16, -1, 5, 4, forward> and <960, 24, 16, -1, 4, 5, forward>
-    assert len(rw) == 4 and sum("Li768ELi24ELi16ELin1ELi5ELi4ELb0E" in n for n in rw) == 2 and \
+    rw = sorted(n for n in names if "msda_rw_d32" in n)       # LocAttnIO + RawIO of <768, 25, 16, -1, 5, 4, forward> and <960, 24, 16, -1, 4, 5, forward>
+    assert len(rw) == 4 and sum("Li768ELi25ELi16ELin1ELi5ELi4ELb0E" in n for n in rw) == 2 and \
         sum("Li960ELi24ELi16ELin1ELi4ELi5ELb0E" in n for n in rw) == 2, rw
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(csrc, "libsemidetr_hip.so")],
                                           capture_output=True, text=True).stdout
