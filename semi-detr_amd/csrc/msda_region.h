@@ -62,7 +62,15 @@ __device__ __forceinline__ void reg_scatter_body(
     const int Lq = S, LP = L * P, rs = M * kD;
     const int m = (b % M + (b / M) / kScatterHeadRun) % M;
     const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
-    const int tid_k = threadIdx.x, tid = tid_k;
+    // the thread index is rebuilt where it is needed (wave number: wave-uniform, lives in a scalar register; lane number: two VALU) so
+    // that neither it nor anything derived from it has to stay in a vector register across the whole kernel (see the region loop)
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    auto fresh_tid = [&]() {
+        unsigned ones = ~0u;
+        asm volatile("" : "+s"(ones));      // (an input the compiler cannot see through: the sum is not hoisted out of the loops and spilled)
+        return wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+    };
+    const int tid = fresh_tid();
 
     // the finest level (most pixels) carries the region grid
     int lb = 0, Hb = (int)shapes[0], Wb = (int)shapes[1];
@@ -87,7 +95,7 @@ __device__ __forceinline__ void reg_scatter_body(
         // the thread index (again per pass below) and the region grid's sizes go through an empty asm: what is derived from them (LDS
         // addresses, piece offsets, float copies, the reciprocal of the division below) is then rebuilt per region / pass instead of
         // living in registers from the kernel's first instruction to its last (102 -> 90 VGPRs)
-        int tid_r = tid_k, Hb_p = Hb_k, Wb_p = Wb_k, nrx_p = nrx_k;
+        int tid_r = fresh_tid(), Hb_p = Hb_k, Wb_p = Wb_k, nrx_p = nrx_k;
         asm volatile("" : "+v"(tid_r), "+s"(Hb_p), "+s"(Wb_p), "+s"(nrx_p));
         const int tid = tid_r, Hb = Hb_p, Wb = Wb_p, nrx = nrx_p;
         const int y0b = (reg / nrx) * RTH, x0b = (reg % nrx) * RTW;
@@ -110,14 +118,17 @@ __device__ __forceinline__ void reg_scatter_body(
             lv[3 * kMaxLevels + tid] = max(yhi - ylo, 0) * max(xhi - xlo, 0);      // count, turned into an offset below
         }
         __syncthreads();
-        int nq_total = 0;
-        for (int l = 0; l < L; ++l) nq_total += lv[3 * kMaxLevels + l];
+        int nq_sum = 0;
+        for (int l = 0; l < L; ++l) nq_sum += lv[3 * kMaxLevels + l];
+        // (wave-uniform values that came through vector registers -- an LDS sum, two float divisions -- go back to scalar registers)
+        const int nq_total = __builtin_amdgcn_readfirstlane(nq_sum);
         // region centre in normalised coordinates (pixel centres are (i + 0.5) / size)
-        const float pcy = (y0b + 0.5f * RTH) / (float)Hb, pcx = (x0b + 0.5f * RTW) / (float)Wb;
+        const float pcy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((y0b + 0.5f * RTH) / (float)Hb)));
+        const float pcx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((x0b + 0.5f * RTW) / (float)Wb)));
 
         for (int q_base = 0; q_base < nq_total; q_base += kRegQ) {      // one pass unless the region has > kRegQ queries
             const int nq = min(kRegQ, nq_total - q_base);
-            int tid_p = tid_k;
+            int tid_p = fresh_tid();
             asm volatile("" : "+v"(tid_p));
             const int tid = tid_p, lane = tid & 63, wv = tid >> 6;
             __syncthreads();
@@ -299,7 +310,7 @@ __device__ __forceinline__ void reg_scatter_body(
                     int incl = v;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) {
-                        const int t = __shfl_up(incl, d, 64);
+                        const int t = __builtin_amdgcn_ds_bpermute((lane - d) << 2, incl);      // (= __shfl_up without its own copy of the lane number)
                         if (lane >= d) incl += t;
                     }
                     if (lane == 63) wsum[wv] = incl;
