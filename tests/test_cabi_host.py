@@ -58,6 +58,26 @@ def test_product_code_object_holds_only_reachable_msda_kernels():
     rw = sorted(n for n in names if "msda_rw_d32" in n)       # LocAttnIO + RawIO of <768, 25, 16, -1, 5, 4, forward> and <960, 24, 16, -1, 4, 5, forward>
     assert len(rw) == 4 and sum("Li768ELi25ELi16ELin1ELi5ELi4ELb0E" in n for n in rw) == 2 and \
         sum("Li960ELi24ELi16ELin1ELi4ELi5ELb0E" in n for n in rw) == 2, rw
+    # no kernel of the product spills registers (scratch is per-lane memory on gfx950: a handful of spilled registers cost the
+    # window forward 30 % and hid the whole gain of the scatter's third workgroup per CU -- DESIGN.md section 6).  The kernel
+    # metadata is msgpack: the key is followed by its integer value.
+    blob = open(os.path.join(csrc, "libsemidetr_hip.so"), "rb").read()
+    spills, at = [], 0
+    for key in (b".vgpr_spill_count", b".sgpr_spill_count"):
+        at = 0
+        while True:
+            at = blob.find(key, at)
+            if at < 0:
+                break
+            v = blob[at + len(key)]
+            if v == 0xcc:
+                v = blob[at + len(key) + 1]
+            elif v == 0xcd:
+                v = int.from_bytes(blob[at + len(key) + 1:at + len(key) + 3], "big")
+            if key == b".vgpr_spill_count":
+                spills.append(v)
+            at += len(key)
+    assert len(spills) >= 40 and max(spills) == 0, spills
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(csrc, "libsemidetr_hip.so")],
                                           capture_output=True, text=True).stdout
     assert kernels >= {"msda_fwd_d32", "msda_rw_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged_wide",
