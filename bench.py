@@ -117,10 +117,19 @@ class StudentParams(torch.nn.Module):
             self.groups[name] = list(ps)
 
 
+MIXED_IMG_SHAPES = [(800, 1333), (800, 1201), (750, 1333), (704, 1066)]      # images of a padded batch; the first one fills the canvas
+
+
 class Workload:
-    def __init__(self, dev, seed, recipe="coco10", io="locattn", input_sets=ROT):
+    def __init__(self, dev, seed, recipe="coco10", io="locattn", input_sets=ROT, masked=False):
+        """masked: the reference's call structure for a batch of images of DIFFERENT sizes (SURVEY 8(d) "a variant with mixed
+        img_shapes to exercise masks"): every MSDeformAttn call gets the padding mask of its batch (transformer.py:1268-1309,
+        :1380 -- the reference passes one even when nothing is padded), reference points are scaled by the valid ratios
+        (:675-691, :975).  io "locattn": `value.masked_fill(mask, 0)` before the op and its backward after it, as
+        ops/modules/ms_deform_attn.py:95-96 does; io "raw": the mask goes into the fused kernels."""
         import semi_detr_amd as sda
         self.sda, self.dev = sda, dev
+        self.masked = bool(masked)
         self.rot = ROT = max(1, int(input_sets))      # noqa: N806 (shadows the module default on purpose)
         rc = RECIPES[recipe]
         self.recipe, self.io = recipe, io
@@ -137,6 +146,27 @@ class Workload:
                                                     (torch.arange(w, device=dev) + 0.5) / w, indexing="ij"),
                                      -1).flip(-1).reshape(-1, 2) for h, w in LV])          # (S, 2) x,y
         inv = torch.tensor([[2.0 / w, 2.0 / h] for h, w in LV], device=dev).view(1, 1, 1, Lx, 1, 2)
+        self.mask, self.valid_ratio = {}, {}
+
+        def geometry(n):
+            """padding mask (n, S) and valid ratios (n, L, 2) [w, h] of n images on the 800 x 1333 canvas (transformer.py:1268-1288,
+            get_valid_ratio :1230-1237); reference points of the encoder = pixel centres / valid extent x valid ratio (:675-691)"""
+            if not self.masked:
+                return ref.view(1, Sx, 1, 2).expand(n, Sx, Lx, 2)
+            mks, vrs, refs = [], [], []
+            for h, w in LV:
+                mk = torch.ones(n, h, w, dtype=torch.bool, device=dev)
+                for i, (ih, iw) in enumerate(MIXED_IMG_SHAPES[:n]):
+                    mk[i, :math.ceil(ih * h / 800), :math.ceil(iw * w / 1333)] = False
+                mks.append(mk.flatten(1))
+                vrs.append(torch.stack([(~mk[:, 0, :]).sum(1).float() / w, (~mk[:, :, 0]).sum(1).float() / h], -1))
+            vr = torch.stack(vrs, 1)
+            for lvl, (h, w) in enumerate(LV):
+                ry, rx = torch.meshgrid((torch.arange(h, device=dev) + 0.5), (torch.arange(w, device=dev) + 0.5), indexing="ij")
+                refs.append(torch.stack((rx.reshape(-1)[None] / (vr[:, None, lvl, 0] * w), ry.reshape(-1)[None] / (vr[:, None, lvl, 1] * h)), -1))
+            self.mask[n] = torch.cat(mks, 1).contiguous()
+            self.valid_ratio[n] = vr
+            return torch.cat(refs, 1)[:, :, None] * vr[:, None]               # (n, S, L, 2)
 
         def rand(*s):
             return torch.rand(*s, generator=g, device=dev)
@@ -159,22 +189,30 @@ class Workload:
         for n in sorted({1, 2, 4} if recipe == "coco10" else {self.n_sup, self.n_unsup}):
             put(("value", n), lambda: rand(n, Sx, M, D) * 0.01)
             put(("enc_gout", n), lambda: rand(n, Sx, M * D))
+            eref = geometry(n)                                                 # (n, S, L, 2)
+            if self.masked and io != "raw":      # what autograd saved for the op's backward: the masked copy of `value`
+                self.t[("value_masked", n)] = [v.masked_fill(self.mask[n][..., None, None], 0.0) for v in self.t[("value", n)]]
             if io == "raw":      # the fused prologue's inputs: reference points, RAW offsets (pixels), RAW logits
-                put(("enc_ref", n), lambda: ref.view(1, Sx, 1, 2).expand(n, Sx, Lx, 2).contiguous())
+                put(("enc_ref", n), lambda: eref.contiguous().clone())
                 put(("enc_off", n), lambda: (randn(n, Sx, M, Lx, P, 2) * 2.0).contiguous())
                 put(("enc_logit", n), lambda: (randn(n, Sx, M, Lx * P) * 2.0).contiguous())
             else:
-                put(("enc_loc", n), lambda: (ref.view(1, Sx, 1, 1, 1, 2) + randn(n, Sx, M, Lx, P, 2) * inv).contiguous())
+                put(("enc_loc", n), lambda: (eref.reshape(n, Sx, 1, Lx, 1, 2) + randn(n, Sx, M, Lx, P, 2) * inv).contiguous())
                 put(("enc_attn", n), lambda: attn(n, Sx))
+            # decoder reference boxes are scaled by the valid ratios per level (transformer.py:975)
+            vr4 = (torch.cat([self.valid_ratio[n]] * 2, -1).view(n, 1, Lx, 4) if self.masked
+                   else torch.ones(1, 1, Lx, 4, device=dev))
             for lq in (NUM_QUERY, NUM_QUERY + DN_PAD):
                 # decoder: reference boxes anywhere, offsets scaled by the box size
                 def dec_set(lq=lq):
                     c = rand(n, lq, 1, 1, 1, 2)
                     wh = rand(n, lq, 1, 1, 1, 2) * 0.3 + 0.02
+                    box = (torch.cat([c, wh], -1).view(n, lq, 1, 4) * vr4).expand(n, lq, Lx, 4)
                     if io == "raw":  # ref_dim 4: loc = c + off / P * wh * 0.5 (ms_deform_attn.py:106-108)
-                        return (torch.cat([c, wh], -1).view(n, lq, 1, 4).expand(n, lq, Lx, 4).contiguous(),
+                        return (box.contiguous(),
                                 (randn(n, lq, M, Lx, P, 2) * P).contiguous(), (randn(n, lq, M, Lx * P) * 2.0).contiguous())
-                    return ((c + randn(n, lq, M, Lx, P, 2) * wh * 0.5).contiguous(), attn(n, lq))
+                    bx = box.reshape(n, lq, 1, Lx, 1, 4)
+                    return ((bx[..., :2] + randn(n, lq, M, Lx, P, 2) * bx[..., 2:] * 0.5).contiguous(), attn(n, lq))
                 sets = [dec_set() for _ in range(ROT)]
                 if io == "raw":
                     self.t[("dec_ref", n, lq)] = [x[0] for x in sets]
@@ -251,9 +289,17 @@ class Workload:
         im2col = () if self.io == "raw" else (64,)
         calls = [(self.t[("value", n)][r % self.rot], self._args(kind, n, lq, r)) for r in range(reps)]      # layer r -> input set r
 
+        mask = self.mask[n] if self.masked else None
+        mask4 = mask[..., None, None] if self.masked else None
+
         def run():
             for v, a in calls:
-                fn(v, self.shapes, self.starts, *a, *im2col)
+                if not self.masked:
+                    fn(v, self.shapes, self.starts, *a, *im2col)
+                elif self.io == "raw":
+                    fn(v, self.shapes, self.starts, *a, mask)
+                else:      # ops/modules/ms_deform_attn.py:95-96
+                    fn(v.masked_fill(mask4, 0.0), self.shapes, self.starts, *a, *im2col)
         name = f"msda_fwd_{kind}_bs{n}_Lq{lq}"
         self._timed(name, reps, self.alg_bytes(n, lq, False), run)
         # (every time: the encoder forward's kernel is chosen from the data of the previous launches, the last call wins)
@@ -264,11 +310,19 @@ class Workload:
         gk = ("enc_gout", n) if kind == "enc" else ("dec_gout", n, lq)
         fn = MSDA.ms_deform_attn_fused_backward if self.io == "raw" else MSDA.ms_deform_attn_backward
         im2col = () if self.io == "raw" else (64,)
-        calls = [(self.t[("value", n)][r % self.rot], self._args(kind, n, lq, r), self.t[gk][r % self.rot]) for r in range(reps)]
+        vk = ("value_masked", n) if self.masked and self.io != "raw" else ("value", n)
+        calls = [(self.t[vk][r % self.rot], self._args(kind, n, lq, r), self.t[gk][r % self.rot]) for r in range(reps)]
+        mask = self.mask[n] if self.masked else None
+        mask4 = mask[..., None, None] if self.masked else None
 
         def run():
             for v, a, go in calls:
-                fn(v, self.shapes, self.starts, *a, go, *im2col)
+                if not self.masked:
+                    fn(v, self.shapes, self.starts, *a, go, *im2col)
+                elif self.io == "raw":
+                    fn(v, self.shapes, self.starts, *a, go, mask)
+                else:      # the op on the masked copy autograd saved, then masked_fill's backward on grad_value
+                    fn(v, self.shapes, self.starts, *a, go, *im2col)[0].masked_fill(mask4, 0.0)
         name = f"msda_bwd_{kind}_bs{n}_Lq{lq}"
         self._timed(name, reps, self.alg_bytes(n, lq, True), run)
         if name not in self.kernels:
@@ -837,10 +891,10 @@ def comm_summary(ddp, stamps):
     return {"exposed_ms_per_step": float(np.mean([p["exposed_ms"] for p in prof])), "bucket_ready_to_done_ms": per_bucket}
 
 
-def run_flavour(dev, seed, recipe, io, steps=5, warmup=2, reuse_encoder=False, input_sets=ROT):
+def run_flavour(dev, seed, recipe, io, steps=5, warmup=2, reuse_encoder=False, input_sets=ROT, masked=False):
     """A short run of another flavour of the step on the same device: ms per step, images/s and the roofline fraction of
     its dominant MSDA group (algorithmic bytes / event-timed launch / 8 TB/s)."""
-    wl = Workload(dev, seed, recipe=recipe, io=io, input_sets=input_sets)
+    wl = Workload(dev, seed, recipe=recipe, io=io, input_sets=input_sets, masked=masked)
     for _ in range(warmup):
         wl.step(reuse_encoder=reuse_encoder)
     torch.cuda.synchronize()
@@ -880,6 +934,10 @@ def main():
                     help="locattn: the reference op contract (sampling locations + softmaxed weights); raw: the fused "
                          "MSDeformAttn prologue / epilogue the product module runs by default (reference points + raw offsets "
                          "+ raw logits)")
+    ap.add_argument("--masked", action="store_true",
+                    help="images of different sizes on the 800 x 1333 canvas: every MSDeformAttn call gets its batch's padding mask "
+                         "and valid-ratio scaled reference points, as the reference's transformer passes them (locattn: masked_fill "
+                         "around the op, ms_deform_attn.py:95-96; raw: the mask goes into the fused kernels)")
     ap.add_argument("--reuse-encoder", action="store_true",
                     help="NOT the reference's call structure (INTEGRATION.md 3.3): the student's and the teacher's second encoder "
                          "pass over identical inputs reuse the first one's memory -- 12 fewer unlabeled-batch encoder forwards")
@@ -909,7 +967,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    wl = Workload(dev, seed=1234 + rank, recipe=args.recipe, io=args.io, input_sets=args.input_sets)
+    wl = Workload(dev, seed=1234 + rank, recipe=args.recipe, io=args.io, input_sets=args.input_sets, masked=args.masked)
     wl.sda._lib.set_forward_policy(args.forward_policy)
     ipg = wl.images_per_gpu
     ddp = None
@@ -1038,7 +1096,7 @@ def main():
                                     "filter + box warp; dense GEMMs/backbone not included")
                                    % ({"coco10": "COCO-10% (BASELINE.json configs[2]/[3])", "full": "COCO-Full (BASELINE.json configs[4])"}[args.recipe],
                                       wl.n_sup, wl.n_unsup, wl.S, wl.L, wl.S, wl.n_match, wl.n_params),
-                       "recipe": args.recipe, "io": args.io, "images_per_gpu": ipg, "reuse_encoder": bool(args.reuse_encoder),
+                       "recipe": args.recipe, "io": args.io, "masked": bool(args.masked), "images_per_gpu": ipg, "reuse_encoder": bool(args.reuse_encoder),
                        "backbone_ms": args.backbone_ms, "input_sets_per_group": wl.rot, "forward_policy": args.forward_policy,
                        "parallelism": "dp%d image-sharded, FlatDDP bucketed grad all-reduce of %d fp32 over RCCL" % (world, GRAD_ELEMS)
                        if world > 1 else "single GPU"},
@@ -1114,17 +1172,24 @@ def main():
             out["encoder_forward_by_sample_spread"] = forward_policy_bench(dev)
             out["module_fused_prologue"] = module_bench(dev)
             out["warmup_stage"] = warmup_stage_bench(dev)
-        if world == 1 and not args.no_flavours and args.recipe == "coco10" and args.io == "locattn" and not args.reuse_encoder:
+        if world == 1 and not args.no_flavours and args.recipe == "coco10" and args.io == "locattn" and not args.reuse_encoder and not args.masked:
             # the other flavours of the step, 5 steps each (the driver's record then answers "COCO-Full images/s" and
             # "fused-path images/s" by itself); the headline above stays the reference-contract COCO-10 % step
             del wl.t
             torch.cuda.empty_cache()
             out["flavours"] = {"raw": run_flavour(dev, 1234, "coco10", "raw"),
+                               "raw_masked": run_flavour(dev, 1234, "coco10", "raw", masked=True),
+                               "masked": run_flavour(dev, 1234, "coco10", "locattn", masked=True),
                                "full": run_flavour(dev, 1234, "full", "locattn"),
                                "full_raw": run_flavour(dev, 1234, "full", "raw"),
                                "reuse_encoder": run_flavour(dev, 1234, "coco10", "locattn", reuse_encoder=True),
                                "replayed_inputs": run_flavour(dev, 1234, "coco10", "locattn", input_sets=1)}
-            out["flavours"]["note"] = ("raw = the fused MSDeformAttn prologue kernels the product module runs by default; full = "
+            out["flavours"]["note"] = ("raw = the fused MSDeformAttn prologue kernels the product module runs by default; raw_masked = the "
+                                       "same with what the reference's transformer really passes: the padding mask of a batch of images of "
+                                       "different sizes in every call (inside the fused kernels) and valid-ratio scaled reference points "
+                                       "-- what a checkout with unchanged configs runs; masked = that batch through the reference op "
+                                       "contract, value.masked_fill(mask, 0) before the op and its backward after it "
+                                       "(ms_deform_attn.py:95-96); full = "
                                        "COCO-Full recipe (BASELINE.json configs[4]: 4 + 4 images, five levels); reuse_encoder = the "
                                        "call-site change of INTEGRATION.md 3.3 (12 fewer encoder forwards), NOT the reference's call "
                                        "structure; replayed_inputs = the headline step with ONE input set per group replayed by all six "

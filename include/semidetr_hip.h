@@ -26,7 +26,7 @@ extern "C" {
 #define SEMIDETR_E_TOOLARGE (-2)    /* an index would overflow the 32-bit arithmetic used on device  */
 #define SEMIDETR_E_NODEVICE (-3)    /* no HIP device available                                        */
 
-#define SEMIDETR_ABI_VERSION 5
+#define SEMIDETR_ABI_VERSION 6
 
 int semidetr_abi_version(void);
 const char *semidetr_last_error(void);
@@ -103,6 +103,12 @@ int semidetr_msda_backward_f64(void *stream, const double *grad_out, const doubl
  *   padding_mask      (batch, spatial_size) bytes, nonzero = padded pixel, or NULL: `value.masked_fill(mask[..., None], 0)`
  *                     (ms_deform_attn.py:95-96) folded in -- a corner on a padded pixel reads as zero and receives no
  *                     gradient, so `value` is passed UNMASKED and grad_value comes back with zero rows there.
+ *   mask_extents      (batch, num_levels) int32 words vh | vw << 16 written by semidetr_msda_mask_extents for THIS padding_mask
+ *                     and level table, or NULL.  DETR's masks mark the band below / right of each image inside the batch canvas
+ *                     (transformer.py:1268-1288), so "pixel (y, x) of level l is padding iff y >= vh or x >= vw" describes them
+ *                     exactly; with it the kernels test a corner with two compares instead of a dependent byte load (which
+ *                     cost +15 % on every kernel).  A level whose mask is not of that form carries -1 and its corners read
+ *                     their bytes, as all corners do when mask_extents is NULL: the results are the mask's either way.
  *   grad_sampling_offsets / grad_attn_logits: same shapes, every element written.
  * (The gradient w.r.t. reference_points, when a caller needs it, follows from grad_sampling_offsets on the
  *  host side; the reference detaches reference points between decoder layers, transformer.py:1033.)
@@ -110,21 +116,28 @@ int semidetr_msda_backward_f64(void *stream, const double *grad_out, const doubl
 int semidetr_msda_fused_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                                     const int64_t *level_start, const float *reference_points, int ref_dim,
                                     const float *sampling_offsets, const float *attn_logits,
-                                    const unsigned char *padding_mask, int batch,
+                                    const unsigned char *padding_mask, const int *mask_extents, int batch,
                                     int spatial_size, int num_heads, int channels, int num_levels,
                                     int num_query, int num_point, int flags, float *out);
 int semidetr_msda_fused_backward_f32(void *stream, const float *grad_out, const float *value,
                                      const int64_t *spatial_shapes, const int64_t *level_start,
                                      const float *reference_points, int ref_dim,
                                      const float *sampling_offsets, const float *attn_logits,
-                                     const unsigned char *padding_mask, int batch,
+                                     const unsigned char *padding_mask, const int *mask_extents, int batch,
                                      int spatial_size, int num_heads, int channels, int num_levels,
                                      int num_query, int num_point, int flags, float *grad_value,
                                      float *grad_sampling_offsets, float *grad_attn_logits);
+/* Summarise a padding mask for the two calls above: one small launch (batch x num_levels workgroups, reads the mask once).
+ *   extents (batch, num_levels) int32: vh | vw << 16 when level l of image n is padded exactly on rows >= vh and columns >= vw
+ *   (no padding: H_l | W_l << 16; everything padded: 0), -1 otherwise (and for levels of more than 32767 rows / columns).  Valid for as long as the mask bytes and the
+ *   level table do not change; the reference builds one mask per batch and hands it to all twelve layers
+ *   (transformer.py:1309,1380), so one call per batch serves 12 forward + 12 backward launches. */
+int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, const int64_t *spatial_shapes,
+                               const int64_t *level_start, int batch, int spatial_size, int num_levels, int *extents);
 
 /* ---------------------------------------------------------------------------------------------
- * Which kernel runs the encoder self-attention FORWARD (SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, four or five levels,
- * no padding mask).  The reference has one kernel for everything (ms_deform_im2col_cuda.cuh:237-299); here two
+ * Which kernel runs the encoder self-attention FORWARD (SEMIDETR_MSDA_QUERIES_ARE_PIXELS, num_point == 4, four or five levels;
+ * with or without a padding mask).  The reference has one kernel for everything (ms_deform_im2col_cuda.cuh:237-299); here two
  * produce the same results at different speeds depending on how far the learned offsets reach:
  *   patch kernel   -- 4 x 8 query patches, every corner row through the vector-memory path; insensitive to the offsets
  *   window kernel  -- regions of up to 25 x 16 pixels, the coarse levels' corner rows from LDS windows +- 5 px (five levels: +- 4 px) around

@@ -12,6 +12,8 @@ re-exports its functions; there is no Python or CPU implementation to fall back 
                             im2col_step) -> [grad_value, grad_sampling_loc, grad_attn_weight]
     ms_deform_attn_fused_forward / ms_deform_attn_fused_backward / fused_supported   
     pyramid_check(spatial_shapes, level_start_index, S) -> bit 0: sum(H*W) == S, bit 1: exact tiling (cached)
+    mask_extents(padding_mask, spatial_shapes, level_start_index) -> (N, L) int32 summary of a padding mask (cached; the
+                                                                      fused calls fetch it themselves)
 """
 import torch  # noqa: F401  (libtorch must be loaded before the extension)
 
@@ -34,6 +36,7 @@ ms_deform_attn_fused_forward = _msda_ext.ms_deform_attn_fused_forward
 ms_deform_attn_fused_backward = _msda_ext.ms_deform_attn_fused_backward
 fused_supported = _msda_ext.fused_supported
 pyramid_check = _msda_ext.pyramid_check
+mask_extents = _msda_ext.mask_extents
 
 if _msda_ext.abi_version() != _lib.lib().semidetr_abi_version():      # a stale front end against a newer library
     raise _lib.NativeLibraryError("semi-detr_amd/_msda_ext*.so was built against ABI %d, libsemidetr_hip.so is ABI %d: rebuild "

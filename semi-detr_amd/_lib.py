@@ -36,8 +36,9 @@ SIGNATURES = {
     "semidetr_msda_forward_f64": (c_int, _MSDA_FWD),
     "semidetr_msda_backward_f32": (c_int, _MSDA_BWD_F32),
     "semidetr_msda_backward_f64": (c_int, _MSDA_BWD),
-    "semidetr_msda_fused_forward_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
-    "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 3 + [c_int] * 8 + [c_void_p] * 3),
+    "semidetr_msda_fused_forward_f32": (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 4 + [c_int] * 8 + [c_void_p]),
+    "semidetr_msda_fused_backward_f32": (c_int, [c_void_p] * 6 + [c_int] + [c_void_p] * 4 + [c_int] * 8 + [c_void_p] * 3),
+    "semidetr_msda_mask_extents": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     "semidetr_msda_last_kernels": (ctypes.c_char_p, []),
     "semidetr_msda_set_forward_policy": (c_int, [c_int]),
     "semidetr_msda_forward_policy_state": (c_int, [c_void_p] * 4),

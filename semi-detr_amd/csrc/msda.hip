@@ -32,6 +32,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #if SEMIDETR_EXPERIMENTS
@@ -509,9 +510,10 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
     hipLaunchKernelGGL((msda_fwd_d32<SP, 4, PT, IO>), dim3((unsigned)((int64_t)N * (TILES) * M)), dim3(256), \
                        (LDS), st, value, spatial_shapes, level_start, io, S, M, L, Lq, P, (TILES), out)
     if (pixels) {
-        // encoder self-attention.  The region-window kernel is built for num_point == 4 and four or five levels and takes no
-        // padding mask (its windows are staged from `value` as it is).
-        const bool window_ok = P == kPT && (L == 4 || L == 5) && !io.has_mask();
+        // encoder self-attention.  The region-window kernel is built for num_point == 4 and four or five levels.  A padding mask
+        // (fused prologue; the reference ALWAYS passes one: transformer.py:1309,1460 -> ops/modules/ms_deform_attn.py:95-96) has its
+        // own instantiation: padded rows are staged as zeros, level 0 drops padded corners from its records (msda_rw.h).
+        const bool window_ok = P == kPT && (L == 4 || L == 5);
         FwdStats fs;
         bool use_window = false;
         if (int rc = fwd_adapt_next(st, window_ok, N, L, fs, use_window)) return rc;
@@ -535,6 +537,15 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             };
             constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5>();
             static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
+            if constexpr (std::is_same<IO, RawIO>::value) {
+                if (io.has_mask()) {
+                    if (L == 4)
+                        return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE, true>,
+                                             wlds4, SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
+                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5, true>, wlds5,
+                                         SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5 * 16);
+                }
+            }
             if (L == 4)
                 return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4,
                                      SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
@@ -593,8 +604,13 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, SEMIDETR_GATHER_WPE, SEMIDETR_GATHER_KB>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound, zero, (int64_t)(fill / 16));
         else if (L * P == 20)        // five levels (COCO-Full recipe)
-            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 20, 408, SEMIDETR_GATHER5_WPE, SEMIDETR_GATHER5_KB>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
+        {
+            // (the fused prologue's instantiation holds its softmax / location arithmetic besides: with 16 corner loads in flight it
+            //  spills at four waves per SIMD since it also carries the padding mask's summary -- 8 in flight: 98 registers)
+            constexpr int kb5 = std::is_same<IO, RawIO>::value ? 2 : SEMIDETR_GATHER5_KB;
+            hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 20, 408, SEMIDETR_GATHER5_WPE, kb5>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound, zero, (int64_t)(fill / 16));
+        }
         else
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
@@ -812,7 +828,8 @@ static int check_fused(const void *value, const void *shapes, const void *starts
 extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                                                const int64_t *level_start, const float *reference_points,
                                                int ref_dim, const float *sampling_offsets,
-                                               const float *attn_logits, const unsigned char *padding_mask, int batch,
+                                               const float *attn_logits, const unsigned char *padding_mask,
+                                               const int *mask_extents, int batch,
                                                int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                                                int num_point, int flags, float *out)
 {
@@ -822,7 +839,7 @@ extern "C" int semidetr_msda_fused_forward_f32(void *stream, const float *value,
     SEMIDETR_REQUIRE(out && ((uintptr_t)out & 15) == 0, SEMIDETR_E_BADARG, "msda_fused_forward: bad output pointer");
     const unsigned ref_bytes = (unsigned)((int64_t)batch * num_query * num_levels * ref_dim * 4);
     const RawIO io = {reference_points, sampling_offsets, attn_logits, nullptr, nullptr, ref_dim, num_heads,
-                      num_levels, padding_mask, spatial_size, ref_bytes};
+                      num_levels, padding_mask, spatial_size, ref_bytes, padding_mask ? mask_extents : nullptr};
     SEMIDETR_REQUIRE(!padding_mask || SEMIDETR_FWD_VARIANT == 0, SEMIDETR_E_BADARG,
                      "msda_fused_forward: the experimental kernel variants do not take a padding mask");
     return dispatch_fast_forward(semidetr::as_stream(stream), value, spatial_shapes, level_start, io, batch,
@@ -833,7 +850,7 @@ extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_
                                                 const int64_t *spatial_shapes, const int64_t *level_start,
                                                 const float *reference_points, int ref_dim,
                                                 const float *sampling_offsets, const float *attn_logits,
-                                                const unsigned char *padding_mask, int batch,
+                                                const unsigned char *padding_mask, const int *mask_extents, int batch,
                                                 int spatial_size, int num_heads, int channels, int num_levels,
                                                 int num_query, int num_point, int flags, float *grad_value,
                                                 float *grad_sampling_offsets, float *grad_attn_logits)
@@ -847,11 +864,52 @@ extern "C" int semidetr_msda_fused_backward_f32(void *stream, const float *grad_
                      SEMIDETR_E_BADARG, "msda_fused_backward: pointers must be 16-byte aligned");
     const unsigned ref_bytes = (unsigned)((int64_t)batch * num_query * num_levels * ref_dim * 4);
     const RawIO io = {reference_points, sampling_offsets, attn_logits, grad_sampling_offsets, grad_attn_logits,
-                      ref_dim, num_heads, num_levels, padding_mask, spatial_size, ref_bytes};
+                      ref_dim, num_heads, num_levels, padding_mask, spatial_size, ref_bytes, padding_mask ? mask_extents : nullptr};
     SEMIDETR_REQUIRE(!padding_mask || SEMIDETR_BWD_VARIANT == 0, SEMIDETR_E_BADARG,
                      "msda_fused_backward: the experimental kernel variants do not take a padding mask");
     return dispatch_fast_backward(semidetr::as_stream(stream), grad_out, value, spatial_shapes, level_start, io, batch,
                                   spatial_size, num_heads, num_levels, num_query, num_point, flags, grad_value);
+}
+
+// ---- padding mask -> one word per (image, level): vh | vw << 16 or -1 (MaskExt, msda_fast.h).  One workgroup per (image, level): the first
+//      padded pixel of row 0 / column 0 gives the candidate (vw, vh); every pixel is then checked against "padding iff y >= vh or
+//      x >= vw" -- exactly what F.interpolate of an image-sized padding band produces (dense_heads/dino_detr_head.py:305-318).
+__global__ __launch_bounds__(256) void msda_mask_extents_kernel(const unsigned char *__restrict__ mask, const int64_t *__restrict__ shapes,
+                                                                const int64_t *__restrict__ starts, int S, int L, int *__restrict__ ext)
+{
+    const int n = (int)blockIdx.x / L, l = (int)blockIdx.x % L;
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+    const unsigned char *mk = mask + (int64_t)n * S + st;
+    __shared__ int s_vh, s_vw, s_bad;
+    if (threadIdx.x == 0) { s_vh = H; s_vw = W; s_bad = 0; }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256)
+        if (mk[x]) atomicMin(&s_vw, x);
+    for (int y = threadIdx.x; y < H; y += 256)
+        if (mk[(int64_t)y * W]) atomicMin(&s_vh, y);
+    __syncthreads();
+    int vh = s_vh, vw = s_vw;
+    if (vh == 0 || vw == 0) vh = vw = 0;      // pixel (0, 0) is padding: only "everything is" has the form
+    bool bad = false;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int y = i / W, x = i - y * W;
+        bad = bad || ((mk[i] != 0) != (y >= vh || x >= vw));
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) ext[blockIdx.x] = (s_bad || H > 0x7fff || W > 0x7fff) ? -1 : (vh | (vw << 16));
+}
+
+extern "C" int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, const int64_t *spatial_shapes,
+                                          const int64_t *level_start, int batch, int spatial_size, int num_levels, int *extents)
+{
+    SEMIDETR_REQUIRE(padding_mask && spatial_shapes && level_start && extents, SEMIDETR_E_BADARG, "msda_mask_extents: null pointer argument");
+    SEMIDETR_REQUIRE(batch > 0 && spatial_size > 0 && num_levels > 0 && num_levels <= kMaxLevels && (int64_t)batch * num_levels < INT32_MAX,
+                     SEMIDETR_E_BADARG, "msda_mask_extents: sizes must be positive (batch=%d spatial_size=%d num_levels=%d)", batch,
+                     spatial_size, num_levels);
+    hipLaunchKernelGGL(msda_mask_extents_kernel, dim3((unsigned)(batch * num_levels)), dim3(256), 0, semidetr::as_stream(stream),
+                       padding_mask, spatial_shapes, level_start, spatial_size, num_levels, extents);
+    return semidetr::launch_status("msda_mask_extents");
 }
 
 extern "C" int semidetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,

@@ -256,6 +256,63 @@ const unsigned char *mask_ptr(const c10::optional<at::Tensor> &mask, const at::T
     return static_cast<const unsigned char *>(m.data_ptr());
 }
 
+// ---- the mask's per-(image, level) extents (include/semidetr_hip.h: semidetr_msda_mask_extents), cached like the pyramid
+// check: the reference builds ONE mask per batch and hands it to all twelve layers of a pass (transformer.py:1309,1380), so
+// one small launch per batch serves 12 forward + 12 backward calls.  Keyed on the mask / level-table tensors (weak references +
+// versions + addresses) and the stream the summary was queued on -- a call on another stream queues its own.
+struct ExtentsEntry {
+    c10::weak_intrusive_ptr<c10::TensorImpl> mask, shapes;
+    uint32_t v_mask, v_shapes;
+    const void *p_mask, *p_shapes, *p_starts, *stream;
+    at::Tensor ext;
+};
+std::mutex g_ext_mutex;
+std::vector<ExtentsEntry> g_ext_cache;
+
+at::Tensor mask_extents(const at::Tensor &m, const at::Tensor &shapes, const at::Tensor &starts)
+{
+    TORCH_CHECK(m.is_cuda() && m.is_contiguous() && m.dim() == 2 && (m.scalar_type() == at::kBool || m.scalar_type() == at::kByte),
+                "mask_extents: padding_mask must be a contiguous (N, S) bool / uint8 CUDA tensor");
+    TORCH_CHECK(shapes.is_cuda() && starts.is_cuda() && shapes.scalar_type() == at::kLong && starts.scalar_type() == at::kLong &&
+                    shapes.is_contiguous() && starts.is_contiguous() && shapes.dim() == 2 && shapes.size(1) == 2 &&
+                    starts.numel() == shapes.size(0),
+                "mask_extents: expected contiguous int64 spatial_shapes (L,2) and level_start_index (L,) on the mask's device");
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(m.device());
+    void *stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(m.device().index()).stream();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    // (inference tensors carry no version counter; a summary computed inside a capture lives in the graph's memory pool)
+    const bool cacheable = !m.is_inference() && !shapes.is_inference() && !capturing;
+    auto *im = m.unsafeGetTensorImpl();
+    auto *is = shapes.unsafeGetTensorImpl();
+    if (cacheable) {
+        std::lock_guard<std::mutex> lock(g_ext_mutex);
+        for (auto &e : g_ext_cache) {
+            if (e.mask._unsafe_get_target() != im || e.shapes._unsafe_get_target() != is || e.stream != stream) continue;
+            auto a = e.mask.lock();
+            auto b = e.shapes.lock();
+            if (a && b && e.v_mask == im->version_counter().current_version() && e.v_shapes == is->version_counter().current_version() &&
+                e.p_mask == m.data_ptr() && e.p_shapes == shapes.data_ptr() && e.p_starts == starts.data_ptr())
+                return e.ext;
+        }
+    }
+    const int N = (int)m.size(0), S = (int)m.size(1), L = (int)shapes.size(0);
+    at::Tensor ext = at::empty({N, L}, m.options().dtype(at::kInt));
+    if (ext.numel() == 0) return ext;
+    check_rc(semidetr_msda_mask_extents(stream, static_cast<const unsigned char *>(m.data_ptr()), shapes.data_ptr<int64_t>(),
+                                        starts.data_ptr<int64_t>(), N, S, L, ext.data_ptr<int>()),
+             "mask_extents");
+    if (cacheable) {
+        std::lock_guard<std::mutex> lock(g_ext_mutex);
+        if (g_ext_cache.size() >= 16) g_ext_cache.erase(g_ext_cache.begin());
+        g_ext_cache.push_back({c10::weak_intrusive_ptr<c10::TensorImpl>(m.getIntrusivePtr()),
+                               c10::weak_intrusive_ptr<c10::TensorImpl>(shapes.getIntrusivePtr()),
+                               im->version_counter().current_version(), is->version_counter().current_version(), m.data_ptr(),
+                               shapes.data_ptr(), starts.data_ptr(), stream, ext});
+    }
+    return ext;
+}
+
 at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tensor &spatial_shapes,
                                         const at::Tensor &level_start_index, const at::Tensor &reference_points,
                                         const at::Tensor &sampling_offsets, const at::Tensor &attn_logits,
@@ -266,10 +323,13 @@ at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tenso
     at::Tensor out = at::empty({d.N, d.Lq, (int64_t)d.M * d.D}, value.options());
     if (out.numel() == 0 || value.numel() == 0) return out.zero_();
     const at::Tensor ref = aligned16(reference_points);
+    const unsigned char *mask = mask_ptr(padding_mask, value, d);
+    at::Tensor ext;      // (kept alive until the launch is queued; the allocator orders its reuse on this stream)
+    if (mask) ext = mask_extents(*padding_mask, spatial_shapes, level_start_index);
     const int rc = semidetr_msda_fused_forward_f32(
         stream_of(value), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(),
         ref.data_ptr<float>(), (int)reference_points.size(-1), sampling_offsets.data_ptr<float>(),
-        attn_logits.data_ptr<float>(), mask_ptr(padding_mask, value, d), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
+        attn_logits.data_ptr<float>(), mask, mask ? ext.data_ptr<int>() : nullptr, d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
         self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), out.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_fused_forward");
     return out;
@@ -290,12 +350,15 @@ std::vector<at::Tensor> ms_deform_attn_fused_backward(const at::Tensor &value, c
     at::Tensor gv = at::empty_like(value), go = at::empty_like(sampling_offsets), gl = at::empty_like(attn_logits);
     if (value.numel() == 0 || go.numel() == 0) return {gv.zero_(), go.zero_(), gl.zero_()};
     const at::Tensor ref = aligned16(reference_points);
+    const unsigned char *mask = mask_ptr(padding_mask, value, d);
+    at::Tensor ext;
+    if (mask) ext = mask_extents(*padding_mask, spatial_shapes, level_start_index);
     const int rc = semidetr_msda_fused_backward_f32(
         stream_of(value), grad_output.data_ptr<float>(), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(),
         level_start_index.data_ptr<int64_t>(), ref.data_ptr<float>(), (int)reference_points.size(-1),
-        sampling_offsets.data_ptr<float>(), attn_logits.data_ptr<float>(), mask_ptr(padding_mask, value, d), d.N, d.S, d.M, d.D,
-        d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), gv.data_ptr<float>(), go.data_ptr<float>(),
-        gl.data_ptr<float>());
+        sampling_offsets.data_ptr<float>(), attn_logits.data_ptr<float>(), mask, mask ? ext.data_ptr<int>() : nullptr, d.N, d.S, d.M,
+        d.D, d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), gv.data_ptr<float>(),
+        go.data_ptr<float>(), gl.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_fused_backward");
     return {gv, go, gl};
 }
@@ -316,6 +379,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("level_start_index"), py::arg("reference_points"), py::arg("sampling_offsets"), py::arg("attn_logits"),
           py::arg("grad_output"), py::arg("padding_mask") = py::none());
     m.def("fused_supported", &fused_supported);
+    m.def("mask_extents", &mask_extents, py::arg("padding_mask"), py::arg("spatial_shapes"), py::arg("level_start_index"),
+          "(N, L) int32 words vh | vw << 16: level l of image n is padded exactly on rows >= vh / columns >= vw, or -1.  Cached per "
+          "(mask, level table) tensors, version and stream; the fused calls fetch it themselves.");
     m.def("pyramid_check", &pyramid_check,
           "bit 0: sum(H*W) == S; bit 1: level_start_index tiles [0, S) exactly.  Cached per tensor pair / version.");
     m.def("abi_version", []() { return SEMIDETR_ABI_VERSION; });      // the header this front end was compiled against

@@ -47,12 +47,27 @@ __device__ __forceinline__ void st_stream2(float *p, const float2 v)
 }
 __device__ __forceinline__ void st_stream1(float *p, float v) { __builtin_nontemporal_store(v, p); }
 
+// The padding mask of one (image, level) summarised (semidetr_msda_mask_extents, msda.hip): DETR's masks mark the band below /
+// right of an image inside the batch canvas (dense_heads/dino_detr_head.py:305-318 -> F.interpolate per level), i.e. a pixel (y, x)
+// is padding iff y >= vh or x >= vw.  With the two numbers a kernel tests a corner with two compares instead of a dependent
+// byte load per corner (+15 % on every kernel, round 5); vh < 0: this level's mask is NOT of that form (or nobody summarised
+// it) -- the corner's byte is read.  Either way the result is the mask's, bit for bit.
+// One word per (image, level): vh | vw << 16, or -1 (levels beyond 32767 rows / columns are never summarised).
+struct MaskExt {
+    int ve;
+    __device__ __forceinline__ bool summarised() const { return ve >= 0; }
+    __device__ __forceinline__ int vh() const { return ve & 0xffff; }
+    __device__ __forceinline__ int vw() const { return (int)((unsigned)ve >> 16); }
+};
+
 struct LocAttnIO {
     const float *loc, *attn;
     float *gloc, *gattn;
     static constexpr bool kSoftmax = false;      // attn already holds probabilities
     __device__ __forceinline__ bool masked(int n, int pixel) const { (void)n; (void)pixel; return false; }
     __host__ __device__ __forceinline__ bool has_mask() const { return false; }
+    __device__ __forceinline__ MaskExt mask_ext(int n, int l) const { (void)n; (void)l; return MaskExt{-1}; }
+    __device__ __forceinline__ void same_dims(int S_, int M_, int L_) const { (void)S_; (void)M_; (void)L_; }
     __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
@@ -120,9 +135,24 @@ struct RawIO {
     const unsigned char *mask;
     int S;
     unsigned ref_bytes;                          // size of `ref` (N * Lq * L * ref_dim floats): bound of its buffer resource
+    const int *mext;                             // (N, L) words per (image, level), see MaskExt; null: none (every corner reads its byte)
     static constexpr bool kSoftmax = true;       // load_w returns a raw logit; the kernel normalises the row
     __device__ __forceinline__ bool masked(int n, int pixel) const { return mask[(int64_t)n * S + pixel] != 0; }
     __host__ __device__ __forceinline__ bool has_mask() const { return mask != nullptr; }
+    // The kernels get S / M / L as arguments of their own: telling the compiler that the copies in here are the same numbers lets it
+    // keep ONE scalar register per dimension (the fused-prologue kernels spill scalar registers as it is).
+    __device__ __forceinline__ void same_dims(int S_, int M_, int L_) const
+    {
+        __builtin_assume(S == S_);
+        __builtin_assume(M == M_);
+        __builtin_assume(L == L_);
+    }
+    // (a 4-byte load whose address depends on (image, level) only: issue it beside the sample's own loads, not behind them)
+    __device__ __forceinline__ MaskExt mask_ext(int n, int l) const
+    {
+        if (!mask || !mext) return MaskExt{-1};
+        return MaskExt{mext[n * L + l]};
+    }
     __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
@@ -210,16 +240,45 @@ struct RawIO {
 };
 
 // Padding mask for the kernels that LOAD / scatter through byte offsets (forward, strips backward, gather): corners whose
-// pixel is masked become kOob.  (x, y) -> top-left pixel exactly as sample_setup_oob derives it.
+// pixel is masked become kOob.  (x, y) -> top-left pixel exactly as sample_setup_oob derives it.  `me` = io.mask_ext(n, level).
 template <typename IO>
-__device__ __forceinline__ void mask_corners_oob(const IO &io, int n, float x, float y, int H, int W, int st, unsigned (&off)[4])
+__device__ __forceinline__ void mask_corners_oob(const IO &io, const MaskExt me, int n, float x, float y, int H, int W, int st,
+                                                 unsigned (&off)[4])
 {
     if (!io.has_mask()) return;
     const int h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f)), w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
+    if (me.summarised()) {      // the level's padding is the band below row vh / right of column vw
+        const int vh = me.vh(), vw = me.vw();
+        const bool y0 = h0 >= vh, y1 = h0 + 1 >= vh, x0 = w0 >= vw, x1 = w0 + 1 >= vw;
+        off[0] = (y0 || x0) ? kOob : off[0];
+        off[1] = (y0 || x1) ? kOob : off[1];
+        off[2] = (y1 || x0) ? kOob : off[2];
+        off[3] = (y1 || x1) ? kOob : off[3];
+        return;
+    }
     const int pix = st + h0 * W + w0;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (off[c] != kOob && io.masked(n, pix + (c & 1) + (c >> 1) * W)) off[c] = kOob;
+}
+// ... and for the scatter kernels, which hold level-local pixel indices (or -1) of the four corners of the cell at (h0, w0)
+template <typename IO>
+__device__ __forceinline__ void mask_corners_idx(const IO &io, const MaskExt me, int n, int h0, int w0, int W, int st_plus_base,
+                                                 int (&off)[4])
+{
+    if (!io.has_mask()) return;
+    if (me.summarised()) {
+        const int vh = me.vh(), vw = me.vw();
+        const bool y0 = h0 >= vh, y1 = h0 + 1 >= vh, x0 = w0 >= vw, x1 = w0 + 1 >= vw;
+        off[0] = (y0 || x0) ? -1 : off[0];
+        off[1] = (y0 || x1) ? -1 : off[1];
+        off[2] = (y1 || x0) ? -1 : off[2];
+        off[3] = (y1 || x1) ? -1 : off[3];
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (off[c] >= 0 && io.masked(n, st_plus_base + (c & 1) + (c >> 1) * W)) off[c] = -1;      // padded pixels receive no gradient
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -491,7 +550,9 @@ __device__ __forceinline__ void fwd_stats_add(const FwdStats &fs, unsigned far, 
         far += __shfl_xor(far, s, 64);
         total += __shfl_xor(total, s, 64);
     }
-    if ((threadIdx.x & 63) == 0 && total) {
+    // (lane number from the exec mask, not from threadIdx: the thread index would stay in a register from the kernel's first
+    //  instruction to this one -- in the five-level region-window kernel that was one of three spilled registers)
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0 && total) {
         atomicAdd(fs.cur, far);
         atomicAdd(fs.cur + 1, total);
         fs.cur[2] = kind;
@@ -527,6 +588,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     const bool fixed_k = (256 % LP) == 0;
     const int lf = ((int)threadIdx.x % LP) / P;
     const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
+    const MaskExt mef = fixed_k ? io.mask_ext(t.n, lf) : MaskExt{-1};      // ... and the summary of the level's padding mask
     // PATCH: tiles_per_image is only a sizing hint for the grid -- a workgroup takes patches slot, slot + hint,
     // ... until the pyramid is exhausted, so any hint >= 1 is correct (the level table is device memory).
     for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
@@ -595,6 +657,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
                 const int l = kk[u] / P;
                 const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
                 const int st = fixed_k ? stf : (int)starts[l];
+                const MaskExt me = fixed_k ? mef : io.mask_ext(t.n, l);
                 if (PATCH != 0 && sampled && l >= 1) {      // (workgroup-uniform: one workgroup in 256 pays for this)
                     constexpr int PW_ = PW ? PW : 1;
                     const float cx = ((float)(pt.x0 + rr[u] % PW_) + 0.5f) / (float)pt.Wq;
@@ -606,7 +669,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
                 if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     w = make_float4(a[u] * (hh * hw), a[u] * (hh * lw), a[u] * (lh * hw), a[u] * (lh * lw));
-                    mask_corners_oob(io, t.n, x[u], y[u], H, W, st, off);
+                    mask_corners_oob(io, me, t.n, x[u], y[u], H, W, st, off);
                 }
             }
             rec_off[rr[u] * LPP + kk[u]] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
@@ -687,6 +750,7 @@ __global__ __launch_bounds__(kWsThreads) void msda_fwd_d32_ws(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int Lq, int P, int hint, float *__restrict__ out)
 {
+    io.same_dims(S, M, L);
     constexpr int RPB = 32, PH = 4, PW = 8;
     extern __shared__ float4 smem[];
     const int LP = L * P, LPP = LP + 1;
@@ -700,6 +764,7 @@ __global__ __launch_bounds__(kWsThreads) void msda_fwd_d32_ws(
     const bool fixed_k = (64 % LP) == 0;
     const int lf = (lane % LP) / P;
     const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
+    const MaskExt mef = fixed_k ? io.mask_ext(t.n, lf) : MaskExt{-1};      // ... and the summary of the level's padding mask
     const bool sm_lds = IO::kSoftmax && !lp_shuffles(LP) && LP <= 64;
 
     auto produce = [&](const Patch &pp, int buf) {
@@ -718,7 +783,7 @@ __global__ __launch_bounds__(kWsThreads) void msda_fwd_d32_ws(
             int rr[2], kk[2], qq[2];
             float x[2], y[2], raw[2];
             int64_t rows[2];
-#pragma unroll
+    #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int s = s0 + 64 * u;
                 rr[u] = min(s / LP, RPB - 1);
@@ -747,11 +812,12 @@ __global__ __launch_bounds__(kWsThreads) void msda_fwd_d32_ws(
                     const int l = kk[u] / P;
                     const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
                     const int st = fixed_k ? stf : (int)starts[l];
+                    const MaskExt me = fixed_k ? mef : io.mask_ext(t.n, l);
                     float lw, lh;
                     if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                         const float hh = 1.f - lh, hw = 1.f - lw;
                         w = make_float4(a[u] * (hh * hw), a[u] * (hh * lw), a[u] * (lh * hw), a[u] * (lh * lw));
-                        mask_corners_oob(io, t.n, x[u], y[u], H, W, st, off);
+                        mask_corners_oob(io, me, t.n, x[u], y[u], H, W, st, off);
                     }
                 }
                 rec_off[rr[u] * LPP + kk[u]] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
@@ -824,6 +890,7 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image,
     float *__restrict__ gvalue)
 {
+    io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
     const int LP = L * P, LPP = LP + 1;
     int4 *rec_off = reinterpret_cast<int4 *>(smem);
@@ -854,12 +921,13 @@ __global__ __launch_bounds__(256) void msda_bwd_d32(
             const int64_t nq = (int64_t)t.n * Lq + q, row = nq * M + t.m;
             float x, y, lw, lh;
             io.load_xy(row, nq, LP, k, l, P, H, W, x, y);
+            const MaskExt me = io.mask_ext(t.n, l);
             // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
             pr.z = sm_lds ? rec_p[r * LPP + k].x : row_softmax(io, row, LP, k, io.load_w(row, LP, k));
             if (sample_setup_oob(x, y, H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                 pr.x = lw;
                 pr.y = lh;
-                mask_corners_oob(io, t.n, x, y, H, W, st, off);
+                mask_corners_oob(io, me, t.n, x, y, H, W, st, off);
             }
         }
         rec_off[r * LPP + k] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
@@ -945,6 +1013,7 @@ __device__ __forceinline__ void gather_body(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image)
 {
+    io.same_dims(S, M, L);
     constexpr int RPB = 32;
     const int LP = L * P, LPP = LP + 1;
     int4 *rec_off = reinterpret_cast<int4 *>(smem);
@@ -964,6 +1033,7 @@ __device__ __forceinline__ void gather_body(
     const bool fixed_k = (256 % LP) == 0;
     const int lf = (tid % LP) / P;
     const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
+    const MaskExt mef = fixed_k ? io.mask_ext((active ? t.n : 0), lf) : MaskExt{-1};      // ... and the summary of the level's padding mask
     // PATCH: tiles_per_image is a grid sizing hint; a workgroup takes patches slot, slot + hint, ... (see the forward)
     for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
 #if SEMIDETR_EXPERIMENTS
@@ -1029,13 +1099,14 @@ __device__ __forceinline__ void gather_body(
             if (qq[u] >= 0) {
                 const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
                 const int st = fixed_k ? stf : (int)starts[l];
+                const MaskExt me = fixed_k ? mef : io.mask_ext(t.n, l);
                 float lw, lh;
                 // kept for skipped samples too: the softmax backward of the fused epilogue needs every probability
                 pr.z = a[u];
                 if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                     pr.x = lw;
                     pr.y = lh;
-                    mask_corners_oob(io, t.n, x[u], y[u], H, W, st, off);
+                    mask_corners_oob(io, me, t.n, x[u], y[u], H, W, st, off);
                 }
             }
             rec_off[rr[u] * LPP + kk[u]] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
@@ -1230,6 +1301,7 @@ __global__ __launch_bounds__(256, WPE) void msda_bwd_gather_d32(
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image,
     float4 *__restrict__ zero = nullptr, int64_t zero_n4 = 0)
 {
+    io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
     // optional side job: zero-fill `zero_n4` float4s (grad_value, which the scatter launch that FOLLOWS accumulates into) --
     // every workgroup clears one contiguous slice with fire-and-forget stores before its gather work
@@ -1281,6 +1353,7 @@ __global__ __launch_bounds__(256, 4) void msda_bwd_gather4_d32(
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image,
     float4 *__restrict__ zero, int64_t zero_n4)
 {
+    io.same_dims(S, M, L);
     static_assert(KLP % 4 == 0 && KLP <= 32, "results are spread over the 4 lanes of a quad");
     constexpr int RPB = 64, PH = 8, PW = 8, LP = KLP, LPP = LP + 1, NM = KLP / 4;
     extern __shared__ float4 smem[];
@@ -1304,6 +1377,7 @@ __global__ __launch_bounds__(256, 4) void msda_bwd_gather4_d32(
     const bool fixed_k = (256 % LP) == 0;
     const int lf = (tid % LP) / P;
     const int Hf = fixed_k ? (int)shapes[2 * lf] : 0, Wf = fixed_k ? (int)shapes[2 * lf + 1] : 0, stf = fixed_k ? (int)starts[lf] : 0;
+    const MaskExt mef = fixed_k ? io.mask_ext(t.n, lf) : MaskExt{-1};      // ... and the summary of the level's padding mask
     const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)t.n * S * M * kD, (unsigned)S * M * kD * 4u);
     for (int tile = t.q0 / RPB;; tile += tiles_per_image) {
         const Patch pt = find_patch<PH, PW>(tile, shapes, starts, L);
@@ -1323,7 +1397,7 @@ __global__ __launch_bounds__(256, 4) void msda_bwd_gather4_d32(
             int rr[2], kk[2], qq[2];
             float x[2], y[2], raw[2];
             int64_t rows[2];
-#pragma unroll
+    #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int s = s0 + 256 * u;
                 rr[u] = min(s / LP, RPB - 1);
@@ -1352,12 +1426,13 @@ __global__ __launch_bounds__(256, 4) void msda_bwd_gather4_d32(
                     const int l = kk[u] / P;
                     const int H = fixed_k ? Hf : (int)shapes[2 * l], W = fixed_k ? Wf : (int)shapes[2 * l + 1];
                     const int st = fixed_k ? stf : (int)starts[l];
+                    const MaskExt me = fixed_k ? mef : io.mask_ext(t.n, l);
                     float lw, lh;
                     pr.z = a[u];      // kept for skipped samples too: the softmax backward needs every probability
                     if (sample_setup_oob(x[u], y[u], H, W, st, (unsigned)rs * 4u, off, lw, lh)) {
                         pr.x = lw;
                         pr.y = lh;
-                        mask_corners_oob(io, t.n, x[u], y[u], H, W, st, off);
+                        mask_corners_oob(io, me, t.n, x[u], y[u], H, W, st, off);
                     }
                 }
                 rec_off[rr[u] * LPP + kk[u]] = make_int4((int)off[0], (int)off[1], (int)off[2], (int)off[3]);
@@ -1496,6 +1571,7 @@ __device__ __forceinline__ void lvl_scatter_body(
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int chunks, int chunk_q,
     float *__restrict__ gvalue, const Wait before_atomics = Wait(), int chunks_b = 0, int chunk_q_b = 0)
 {
+    io.same_dims(S, M, L);
     constexpr int kLvlQ = LQ;            // (shadows the file-scope default)
     constexpr int kStreams = NT / 16;
     // layout: gtile [kLvlQ * 32 floats] | entries [emax float2] | cnt [kLvlRows] | start [kLvlRows]
@@ -1514,6 +1590,7 @@ __device__ __forceinline__ void lvl_scatter_body(
     const int l = b % L; b /= L;
     const int ch = b % chunks, n = b / chunks;
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+    const MaskExt me = io.mask_ext(n, l);      // (workgroup-uniform: one image, one level)
     const int R = H * W;
     const bool bucket = R <= kLvlRows;
     if (bucket && chunks_b > 0) {
@@ -1603,10 +1680,10 @@ __device__ __forceinline__ void lvl_scatter_body(
         int off[4];
         float lw, lh;
         if (sidx >= nsamp || !sample_setup(sx[sp], sy[sp], H, W, 0, 1, off, lw, lh)) continue;   // off = level-local pixel or -1
-        if (io.has_mask())
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
-                if (off[ci] >= 0 && io.masked(n, st + off[ci])) off[ci] = -1;      // padded pixels receive no gradient
+        if (io.has_mask()) {      // padded pixels receive no gradient
+            const int h0 = (int)floorf(sub_rn(mul_rn(sy[sp], (float)H), 0.5f)), w0 = (int)floorf(sub_rn(mul_rn(sx[sp], (float)W), 0.5f));
+            mask_corners_idx(io, me, n, h0, w0, W, st + h0 * W + w0, off);
+        }
         const float a = sa[sp];
         const float hh = 1.f - lh, hwt = 1.f - lw;
         cw[sp][0] = hh * hwt * a; cw[sp][1] = hh * lw * a; cw[sp][2] = lh * hwt * a; cw[sp][3] = lh * lw * a;
@@ -1779,6 +1856,7 @@ __global__ __launch_bounds__(kLvlThreadsWide) void msda_bwd_lvl_merged_wide(
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int Lq, int P, int chunks, int chunk_q,
     int chunks_b, int chunk_q_b, int scatter_blocks, int gather_tiles, int gather_blocks, float *__restrict__ gvalue)
 {
+    io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
     if ((int)blockIdx.x < scatter_blocks) {
         lvl_scatter_body<IO, NoWait, kLvlThreadsWide, kLvlQWide>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, Lq, P,

@@ -37,6 +37,7 @@ __device__ __forceinline__ void reg_scatter_body(
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue,
     const float *__restrict__ value = nullptr)
 {
+    io.same_dims(S, M, L);
     constexpr int kWR = WH * WW, kNE = kRegQ * kPT * 4, SPT = (kRegQ * kPT + NT - 1) / NT, KC = (kWR + NT - 1) / NT;
     // WU >= 1000: PAIRED corners.  The left and the right corner of a sample's top (bottom) edge land on NEIGHBOURING window rows, so
     // one 16-byte entry {w_left, w_right, word} bucketed by the LEFT row serves both: half the entries to count, fill and walk; the
@@ -208,6 +209,7 @@ __device__ __forceinline__ void reg_scatter_body(
             lap(0);                  // 0: region set-up (query list, softmax statistics, sampling data, grad_out staging)
             for (int l = 0; l < L; ++l) {
                 const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)starts[l];
+                const MaskExt me = io.mask_ext(n, l);      // (workgroup-uniform)
                 // window: where the region centre maps to on this level, minus half the window
                 const int y0 = (int)floorf(pcy * H - 0.5f) - WH / 2 + 1;
                 const int x0 = (int)floorf(pcx * W - 0.5f) - WW / 2 + 1;
@@ -241,10 +243,8 @@ __device__ __forceinline__ void reg_scatter_body(
                             if (IO::kSoftmax) a = __expf(a - sm_max[sp]) * sm_inv[sp];
                             h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
                             w0 = (int)floorf(sub_rn(mul_rn(x, (float)W), 0.5f));
-                            if (io.has_mask())      // padded pixels receive no gradient (fused prologue, see RawIO)
-#pragma unroll
-                                for (int cidx = 0; cidx < 4; ++cidx)
-                                    if (off[cidx] >= 0 && io.masked(n, st + h0 * W + w0 + (cidx & 1) + (cidx >> 1) * W)) off[cidx] = -1;
+                            // padded pixels receive no gradient (fused prologue, see RawIO)
+                            mask_corners_idx(io, me, n, h0, w0, W, st + h0 * W + w0, off);
                         }
                     }
                     s_lw[sp] = lw;
@@ -671,6 +671,7 @@ __global__ __launch_bounds__(NT, WPE) void msda_bwd_scatter_d32_reg(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
 {
+    io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
     reg_scatter_body<IO, NT, kRegQ, RTH, RTW, WH, WW, DBG, WU>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L,
                                                           regions_bound, gvalue);
@@ -683,6 +684,7 @@ __global__ __launch_bounds__(512, 6) void msda_bwd_scatter_d32_reg_pair_aid(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
 {
+    io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
     reg_scatter_body<IO, 512, 176, 8, 16, 24, 32, 0, 1004, 0, AID>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, regions_bound, gvalue);
 }
@@ -692,6 +694,7 @@ __global__ __launch_bounds__(512, 4) void msda_bwd_scatter_d32_reg_noatomics(
     const float *__restrict__ gout, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
 {
+    io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
     reg_scatter_body<IO, 512, 208, 8, 16, 24, 32, 0, 8, 0, 2>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L, regions_bound, gvalue);
 }
@@ -709,6 +712,7 @@ __global__ __launch_bounds__(NT, WPE) void msda_bwd_enc_fused_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int regions_bound, float *__restrict__ gvalue)
 {
+    io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
     reg_scatter_body<IO, NT, kRegQ, RTH, RTW, WH, WW, DBG, WU, FZ, AID>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L,
                                                                    regions_bound, gvalue, value);
@@ -726,6 +730,7 @@ __global__ __launch_bounds__(512, 4) void msda_bwd_encreg_merged(
     const int64_t *__restrict__ starts, const IO io, int S, int M, int L, int P, int regions_bound, int scatter_blocks,
     int gather_bound, int gather_blocks, int scatter_groups, int period, float *__restrict__ gvalue)
 {
+    io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
     const int b = (int)blockIdx.x, g = b >> 3, lane8 = b & 7;
     const bool is_scatter = (g % period == 0) && (g / period < scatter_groups);

@@ -82,6 +82,12 @@ constexpr int rw_oct_bytes()      // per octet: {float4 record} and {two 16-bit 
     return raw + (raw % 128 == 0 ? 16 : 0);      // octet pitch: A, B, C, D on distinct banks
 }
 
+// Padding mask (MASK instantiations, fused prologue only: ops/modules/ms_deform_attn.py:95-96 `value.masked_fill(mask[..., None], 0)`).
+// The windows are staged with the padded rows as zeros; level 0, which has no window, drops padded corners from its records.  What
+// is padding comes from the level's summary {vh, vw} (MaskExt, msda_fast.h: rows >= vh / columns >= vw -- every mask DETR builds) as two
+// compares per row / corner; a level without one (vh < 0) reads the mask's bytes: beside the staging loads for the windows (no
+// dependent load), from global memory for level-0 corners and out-of-window samples (correct for any mask; only the summarised
+// form is fast).
 template <int NT, int RTH, int RTW, int H0, int HC, int KL, int TUNE = 0>
 constexpr size_t rw_lds_bytes()
 {
@@ -145,12 +151,13 @@ __device__ __forceinline__ void rw_fma4(float4 &acc, const float4 &w, const floa
 //         16  the prefetched sampling data stay as loaded; the fused prologue's location arithmetic runs in the consuming round
 //         32  window addresses by v_mad_u32_u16, packed FMAs with explicit op_sel (measured level; experiments)
 //        Product: 1920 = 16 + 2 + 1, two samples per barrier (four levels); 1110 = 8 + 2 + 1, one sample per barrier (five levels).
-template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GATHER, int DBG = 0, int TUNE = 42>
+template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GATHER, int DBG = 0, int TUNE = 42, bool MASK = false>
 __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(      // 256-thread workgroups: two per CU
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int regions_bound, float *__restrict__ out,
     float4 *__restrict__ zero, int64_t zero_n4, const FwdStats fs = FwdStats{nullptr, nullptr, nullptr, nullptr})
 {
+    io.same_dims(S, M, KL);
     using Wn = RwWin<RTH, RTW, H0, HC, KL>;
     constexpr int P = kPT, KLP = KL * P, G = NT / 8, NPASS = (KLP + 7) / 8;
     constexpr bool FG = Wn::fine_global;                  // level 0 through global loads (forward only)
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
     static_assert(P == 4 && KLP <= 32, "lane j of an octet owns samples j, j + 8, ...");
     static_assert(kOctBytes % 16 == 0, "records are read with ds_read_b128");
+    static_assert(!MASK || (FG && !GATHER), "the padding mask is built into the product configuration: forward, level 0 through global loads");
 
     extern __shared__ float4 smem[];
     char *const lds = reinterpret_cast<char *>(smem);
@@ -219,6 +227,33 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)n * S * M * kD, (unsigned)S * M * kD * 4u);
     const unsigned lane_b = (unsigned)(m * kD + 4 * j8) * 4u;
     const unsigned row_bytes = (unsigned)rs * 4u;
+    // MASK: this image's (S,) padding bytes.  Rebuilt where it is used (the image index goes through an empty asm): as a kernel-long
+    // value the pointer was the scalar register pair that pushed another one out to scratch.
+    const unsigned char *mask_n = nullptr;
+    if constexpr (MASK) mask_n = io.mask + (int64_t)n * S;
+    auto mask_of_image = [&]() -> const unsigned char * {
+        if constexpr (MASK) {
+            int n_ = n;
+            asm volatile("" : "+s"(n_));
+            return io.mask + (int64_t)n_ * S;
+        } else {
+            return nullptr;
+        }
+    };
+    // ... and each level's summary {vh, vw} (MaskExt, msda_fast.h: padding = rows >= vh or columns >= vw; vh < 0: not of that form,
+    // the bytes decide) in lane `level` of every wave, like r_H: two compares per corner instead of a byte per corner
+    // (wave-uniform words: as scalar values they cost spill LANES of a register the kernel holds anyway; one more vector register
+    //  for all of the kernel made the five-level instantiation spill)
+    int ves[KL];
+#pragma unroll
+    for (int l = 0; l < KL; ++l) ves[l] = -1;
+    if constexpr (MASK) {
+        const int r_ve = lane < KL ? io.mask_ext(n, lane).ve : -1;
+#pragma unroll
+        for (int l = 0; l < KL; ++l) ves[l] = __builtin_amdgcn_readlane(r_ve, l);
+    }
+    auto ext_vh = [](int ve) { return ve < 0 ? -1 : (ve & 0xffff); };
+    auto ext_vw = [](int ve) { return ve < 0 ? -1 : (int)((unsigned)ve >> 16); };
 
     // the level of this lane's sample in pass p (sample k = j8 + 8 p, level k / 4) and its static constants
     int myl[NPASS], myH[NPASS], myW[NPASS], myst[NPASS], my_wh1[NPASS], my_ww1[NPASS], my_ww[NPASS], my_row0[NPASS];
@@ -381,6 +416,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             constexpr int RPS = NT / 8;                                   // window rows covered per step (8 lanes per row)
             constexpr int kMaxSteps = (Wn::zrow + RPS - 1) / RPS + KL;
             float4 sv[kMaxSteps];
+            unsigned smk[MASK ? kMaxSteps : 1];      // MASK: the staged rows' padding bytes, loaded beside the rows (no dependent load)
             int tids = tid;    // lean builds: the per-thread window coordinates below are rebuilt per region, not kept in registers
             if (kLean) asm volatile("" : "+v"(tids));
             const int ocs = tids >> 3, j8s = tids & 7;
@@ -396,6 +432,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         const int py = wy0[l] + wy, px = wx0[l] + wx;
                         const bool ok = r < rows_ && (unsigned)py < (unsigned)Hs[l] && (unsigned)px < (unsigned)Ws[l];
                         const unsigned goff = ok ? (unsigned)(sts[l] + py * Ws[l] + px) * row_bytes + lane_bs : kOob;
+                        // (a level with a summary needs no bytes: wave-uniform branch; a row that is not loaded reads byte 0 and ignores it)
+                        if constexpr (MASK) {
+                            smk[nst] = 0u;
+                            if (ves[l] < 0) smk[nst] = mask_n[ok ? sts[l] + py * Ws[l] + px : 0];
+                        }
                         sv[nst++] = buf_ld4(vr, goff);
                         r += RPS;
                         wx += RPS % ww_;
@@ -411,10 +452,19 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 int ist = 0;
 #pragma unroll
                 for (int l = 0; l < KL; ++l) {
-                    const int rows_ = Wn::rows(l);
-                    int r = ocs;
+                    const int ww_ = Wn::ww(l), rows_ = Wn::rows(l);
+                    int r = ocs, wy = ocs / ww_, wx = ocs - wy * ww_;
+                    const int ve_l = ves[l], vh_l = ext_vh(ve_l), vw_l = ext_vw(ve_l);
+                    (void)wy; (void)wx; (void)vh_l; (void)vw_l;
 #pragma unroll
                     for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
+                        if constexpr (MASK) {      // a padded pixel's row is staged as zeros: value.masked_fill(mask, 0)
+                            const bool pad = vh_l >= 0 ? (wy0[l] + wy >= vh_l || wx0[l] + wx >= vw_l) : smk[ist] != 0;
+                            if (pad) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            wx += RPS % ww_;
+                            wy += RPS / ww_;
+                            if (wx >= ww_) { wx -= ww_; ++wy; }
+                        }
                         if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8s * 16) = sv[ist];
                         ++ist;
                         r += RPS;
@@ -530,9 +580,26 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     const bool top = h0 >= 0, bot = h0 + 1 <= c.H - 1, lef = w0 >= 0, rig = w0 + 1 <= c.W - 1;
                     const unsigned base = (unsigned)(c.st + h0 * c.W + w0) * row_bytes;      // may wrap for -1: unused then
                     const unsigned wrow = (unsigned)c.W * row_bytes;
+                    bool c_tl = inside && top && lef, c_tr = inside && top && rig, c_bl = inside && bot && lef, c_br = inside && bot && rig;
+                    if constexpr (MASK) {
+                        // padded corners read as zero.  With the level's summary: two compares per corner; without: its bytes
+                        const int ve0 = ves[0], vh0 = ext_vh(ve0), vw0 = ext_vw(ve0);
+                        if (vh0 >= 0) {
+                            const bool py0 = h0 >= vh0, py1 = h0 + 1 >= vh0, px0 = w0 >= vw0, px1 = w0 + 1 >= vw0;
+                            c_tl = c_tl && !(py0 || px0);
+                            c_tr = c_tr && !(py0 || px1);
+                            c_bl = c_bl && !(py1 || px0);
+                            c_br = c_br && !(py1 || px1);
+                        } else if (inside) {
+                            const unsigned char *gp = mask_of_image() + (c.st + h0 * c.W + w0);
+                            c_tl = c_tl && !gp[0];      // (evaluated left to right: a corner outside the level is never dereferenced)
+                            c_tr = c_tr && !gp[1];
+                            c_bl = c_bl && !gp[c.W];
+                            c_br = c_br && !gp[c.W + 1];
+                        }
+                    }
                     *reinterpret_cast<uint4 *>(orec + kFineAt + k * 32) = make_uint4(
-                        inside && top && lef ? base : kOob, inside && top && rig ? base + row_bytes : kOob,
-                        inside && bot && lef ? base + wrow : kOob, inside && bot && rig ? base + wrow + row_bytes : kOob);
+                        c_tl ? base : kOob, c_tr ? base + row_bytes : kOob, c_bl ? base + wrow : kOob, c_br ? base + wrow + row_bytes : kOob);
                     if (!GATHER)
                         *reinterpret_cast<float4 *>(orec + kFineAt + k * 32 + 16) = inside
                             ? make_float4(a * (hh * hw), a * (hh * lw), a * (lh * hw), a * (lh * lw)) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -604,6 +671,14 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             } while (0)
             // publish sample k's global corner offsets + geometry in slot `sl` of the octet (owner lane only)
             auto publish = [&](bool act, int k, int sl) {
+                MaskExt pme = MaskExt{-1};      // MASK: the summary of sample k's level (fetched with every lane active: a
+                if constexpr (MASK) {               //       shuffle inside the owner-lane branch would read disabled lanes)
+                    const int lv = min(k / P, KL - 1);
+                    int ve = ves[0];
+#pragma unroll
+                    for (int l = 1; l < KL; ++l) ve = lv == l ? ves[l] : ve;
+                    pme = MaskExt{ve};
+                }
                 if (act && j8 == (k & 7)) {
                     const int p = k >> 3;
                     unsigned off[4];
@@ -618,6 +693,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                             px_ = sx[pp]; py_ = sy[pp]; a_ = sa[pp]; H_ = c.H; W_ = c.W; st_ = c.st;
                         }
                     sample_setup_oob(px_, py_, H_, W_, st_, row_bytes, off, lw, lh);
+                    if constexpr (MASK) mask_corners_oob(io, pme, n, px_, py_, H_, W_, st_, off);
                     *reinterpret_cast<uint4 *>(orec + kSlotAt + 32 * sl) = make_uint4(off[0], off[1], off[2], off[3]);
                     *reinterpret_cast<float4 *>(orec + kSlotAt + 32 * sl + 16) = make_float4(lw, lh, a_, 0.f);
                 }

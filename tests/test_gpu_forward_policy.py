@@ -4,7 +4,9 @@
   * parity: patch kernel (policy "patch") and region-window kernel (policy "window") against the CPU oracle on the same
     inputs -- small pyramids incl. ragged edges / far samples / samples outside the map, the full-size bs-4 encoder shape
     for the reference contract AND the fused prologue (four levels and the five-level COCO-Full pyramid), and the patch
-    kernel's results where the window kernel does not apply (padding mask, six levels);
+    kernel's results where the window kernel does not apply (six levels); the fused prologue WITH a padding mask -- what the
+    reference's encoder always passes -- through both kernels: small pyramids with band / random / whole-image padding at three
+    sample spreads, and four images of different sizes on the full-size canvas;
   * the adaptive policy: close samples move the dispatcher to the window kernel, far ones move it back, and what the
     library reports as launched is what the policy state says.
 """
@@ -95,7 +97,7 @@ def test_window_forward_full_size_vs_oracle(io, levels):
 
 
 def test_window_policy_keeps_the_patch_kernel_where_the_window_kernel_does_not_apply():
-    """Six levels, a padding mask: policy "window" must fall back to the patch kernel (and give its results)."""
+    """Six levels: policy "window" must fall back to the patch kernel (and give its results)."""
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd as sda
     sda._lib.set_forward_policy("window")
@@ -110,18 +112,128 @@ def test_window_policy_keeps_the_patch_kernel_where_the_window_kernel_does_not_a
         out = MSDA.ms_deform_attn_forward(_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)
         assert _last() == "msda_fwd_d32<1, 4, 408", (N, len(shapes), _last())
         np.testing.assert_allclose(out.cpu().numpy(), oracle.msda_forward(value, shp, loc, attn), rtol=0, atol=2e-6)
-    # fused prologue with a padding mask
-    value, shp, ref, off, logits, _ = _encoder_case(2, [(20, 27), (10, 14), (5, 7), (3, 4)], 2.0, 3)
-    S = value.shape[1]
-    mask = np.zeros((2, S), np.uint8)
-    mask[1, ::7] = 1
+
+
+def _band_mask(shp, fracs):
+    """Padding as the reference builds it (detr_od/models/dense_heads/dino_detr_head.py:305-318: images smaller than the batch
+    canvas): on every level the bottom / right band beyond (fh * H, fw * W) of image n is padding.  (N, S) bool."""
+    rows = []
+    for fh, fw in fracs:
+        per = []
+        for h, w in shp:
+            mk = np.zeros((int(h), int(w)), bool)
+            mk[int(np.ceil(fh * h)):, :] = True
+            mk[:, int(np.ceil(fw * w)):] = True
+            per.append(mk.reshape(-1))
+        rows.append(np.concatenate(per))
+    return np.stack(rows)
+
+
+def test_mask_extents_summary():
+    """semidetr_msda_mask_extents: vh | vw << 16 exactly when a level's padding is "rows >= vh or columns >= vw", -1 otherwise;
+    the cached answer follows in-place changes of the mask (version counter)."""
+    import MultiScaleDeformableAttention as MSDA
+    shapes = [(37, 53), (19, 27), (10, 14), (5, 7), (1, 1)]
+    shp = np.asarray(shapes, np.int64)
+    st = np.concatenate([[0], np.cumsum(shp[:, 0] * shp[:, 1])])
+    mask = _band_mask(shp, [(1.0, 1.0), (0.8, 0.55), (0.0, 0.3), (0.5, 1.0), (1.0, 0.5)])
+    mask[3, st[1] + 2 * 27 + 5] = True              # image 3, level 1: a padded pixel inside the valid area
+    mask[4, st[3] - 1] = False                      # image 4, level 2: a valid pixel inside the band
+    want = []
+    for fh, fw in [(1.0, 1.0), (0.8, 0.55), (0.0, 0.3), (0.5, 1.0), (1.0, 0.5)]:
+        want.append([[int(np.ceil(fh * h)), int(np.ceil(fw * w))] for h, w in shapes])
+    want = np.asarray(want)
+    want[2] = 0                                     # nothing valid: {0, 0} whatever the other extent says
+    want = want[..., 0] | (want[..., 1] << 16)
+    want[3, 1] = -1
+    want[4, 2] = -1
+    tsh, tm = _t(shp), _t(mask)
+    tls = _starts(tsh)
+    got = MSDA.mask_extents(tm, tsh, tls)
+    assert got.dtype == torch.int32 and tuple(got.shape) == (5, 5)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert MSDA.mask_extents(tm, tsh, tls).data_ptr() == got.data_ptr()          # cached
+    tm[3, int(st[1]) + 2 * 27 + 5] = False                                        # in place: the version moves, the summary follows
+    want[3, 1] = int(np.ceil(0.5 * 19)) | (27 << 16)
+    np.testing.assert_array_equal(MSDA.mask_extents(tm, tsh, tls).cpu().numpy(), want)
+    np.testing.assert_array_equal(MSDA.mask_extents(tm.to(torch.uint8), tsh, tls).cpu().numpy(), want)
+    rnd = _t(np.random.default_rng(0).random((2, int(st[-1]))) < 0.5)
+    assert (MSDA.mask_extents(rnd, tsh, tls)[:, :4] == -1).all()
+
+
+def _masked_fused_forward(value, shp, ref, off, logits, mask):
+    import MultiScaleDeformableAttention as MSDA
     tsh = _t(shp)
-    out = MSDA.ms_deform_attn_fused_forward(_t(value), tsh, _starts(tsh), _t(ref), _t(off), _t(logits), _t(mask).bool())
-    assert _last() == "msda_fwd_d32<1, 4, 408"
+    return MSDA.ms_deform_attn_fused_forward(_t(value), tsh, _starts(tsh), _t(ref), _t(off), _t(logits), _t(mask))
+
+
+@pytest.mark.parametrize("shapes", [[(37, 53), (19, 27), (10, 14), (5, 7)], [(37, 53), (19, 27), (10, 14), (5, 7), (3, 4)],
+                                    [(16, 16), (16, 16), (15, 17), (2, 2)]], ids=["four_levels", "five_levels", "no_pyramid"])
+@pytest.mark.parametrize("kind", ["band", "band_with_holes", "random", "one_image_all_padding", "no_padding"])
+@pytest.mark.parametrize("sigma", [2.0, 9.0, 40.0], ids=["near", "past_the_mask_window", "anywhere"])
+def test_window_forward_with_padding_mask_vs_oracle(shapes, kind, sigma):
+    """The reference ALWAYS hands MSDeformAttn a padding mask (transformer.py:1309,1460), so the fused prologue's default path
+    must reach the region-window kernel with one: staged rows of padded pixels are zeros, level-0 corners come
+    from the LDS mask window (sigma 2 px), from global mask bytes (9 px: beyond the window's 8-pixel margin) and through the
+    out-of-window path of the coarse levels (40 px) -- all equal to the oracle on `value.masked_fill(mask, 0)`
+    (ops/modules/ms_deform_attn.py:95-96).  Padded pixels hold NaN: they must never reach a result."""
+    import semi_detr_amd as sda
+    N = 3
+    value, shp, ref, off, logits, _ = _encoder_case(N, shapes, sigma, int(sigma) + len(shapes))
+    S = value.shape[1]
+    rng = np.random.default_rng(17)
+    if kind == "band":                  # every level summarised as {vh, vw}: corners are tested with two compares
+        mask = _band_mask(shp, [(1.0, 1.0), (0.8, 0.55), (0.47, 0.93)])
+    elif kind == "band_with_holes":     # levels 1 and 3 of image 1 are NOT a band (one more padded / one valid pixel): those two read bytes
+        mask = _band_mask(shp, [(1.0, 1.0), (0.8, 0.55), (0.47, 0.93)])
+        st = np.concatenate([[0], np.cumsum(shp[:, 0] * shp[:, 1])])
+        mask[1, st[1] + 3] = True
+        mask[1, st[4] - 1] = False
+    elif kind == "random":              # no level has the form: every corner reads its byte
+        mask = rng.random((N, S)) < 0.15
+    elif kind == "one_image_all_padding":
+        mask = np.zeros((N, S), bool)
+        mask[1] = True
+    else:
+        mask = np.zeros((N, S), bool)
     loc, attn = _prologue_np(ref, off, logits, shp, P)
     vm = value.copy()
-    vm[mask.astype(bool)] = 0
-    np.testing.assert_allclose(out.cpu().numpy(), oracle.msda_forward(vm, shp, loc, attn), rtol=0, atol=2e-6)
+    vm[mask] = 0
+    want = oracle.msda_forward(vm, shp, loc, attn)
+    value[mask] = np.nan
+    for policy, kernel in (("window", "msda_rw_d32"), ("patch", "msda_fwd_d32<1, 4, 408")):
+        sda._lib.set_forward_policy(policy)
+        out = _masked_fused_forward(value, shp, ref, off, logits, mask)
+        assert _last() == kernel, (policy, _last())
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6, err_msg=policy)
+
+
+@pytest.mark.parametrize("levels", [LEVELS, LEVELS + [(7, 11)]], ids=["four_levels", "five_levels"])
+def test_window_forward_full_size_mixed_image_shapes_vs_oracle(levels):
+    """N = 4 images of DIFFERENT sizes on one 800 x 1333 canvas (the step's encoder call: `mask_flatten` of a padded batch),
+    Lq = S, sigma 2 px: fused prologue + mask through the window kernel, every element against the oracle; and the backward of
+    the same call (patch gather + region scatter) leaves exactly zero gradient on the padded rows."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd as sda
+    value, shp, ref, off, logits, gout = _encoder_case(4, levels, 2.0, 23)
+    mask = _band_mask(shp, [(1.0, 1.0), (0.85, 0.6), (0.6, 1.0), (0.75, 0.75)])
+    assert 0.2 < mask.mean() < 0.4
+    loc, attn = _prologue_np(ref, off, logits, shp, P)
+    vm = value.copy()
+    vm[mask] = 0
+    want = oracle.msda_forward(vm, shp, loc, attn)
+    o_gv, _, _ = oracle.msda_backward(vm, shp, loc, attn, gout)
+    o_gv[mask] = 0                                                # masked_fill's backward
+    value[mask] = np.nan
+    sda._lib.set_forward_policy("window")
+    out = _masked_fused_forward(value, shp, ref, off, logits, mask)
+    assert _last() == "msda_rw_d32"
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6)
+    tsh = _t(shp)
+    gv, _, _ = MSDA.ms_deform_attn_fused_backward(_t(value), tsh, _starts(tsh), _t(ref), _t(off), _t(logits), _t(gout), _t(mask))
+    gv = gv.cpu().numpy()
+    assert np.all(gv[mask] == 0.0), "padded pixels must receive exactly zero gradient"
+    np.testing.assert_allclose(gv, o_gv, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gv).max())))
 
 
 def test_adaptive_policy_follows_the_sample_spread():
