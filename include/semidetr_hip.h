@@ -4,8 +4,8 @@
  * Drop-in boundary: plain pointers + sizes, no torch types.  All pointers are DEVICE pointers unless
  * the parameter is documented as host.  `stream` is a hipStream_t passed as void* (NULL = the null
  * stream).  Every call is asynchronous on `stream`, keeps no global state between calls (apart from a
- * thread-local last-error string and the per-device forward-kernel choice documented at
- * semidetr_msda_set_forward_policy) and is re-entrant.  Return value: 0 on success, otherwise a
+ * thread-local last-error string and the per-(device, call site) forward-kernel choice documented at
+ * semidetr_msda_set_forward_policy, which also lists the one-time allocation it makes) and is re-entrant.  Return value: 0 on success, otherwise a
  * SEMIDETR_E_* code (negative: argument/precondition error detected on the host; positive: the
  * hipError_t returned by the launch).  semidetr_last_error() gives the message for the calling thread.
  *
@@ -65,6 +65,17 @@ const char *semidetr_last_error(void);
  * grad_value inside its first kernel; grad_value of the encoder path is produced by the region-owned scatter.
  * ------------------------------------------------------------------------------------------- */
 #define SEMIDETR_MSDA_QUERIES_ARE_PIXELS 1
+/* Bits 8..15 of `flags`: the call site's slot of the forward-kernel choice (semidetr_msda_set_forward_policy below), 0..255.
+ * The reference builds twelve MSDeformAttn instances per model (transformer.py:609,760); give each its own slot and its
+ * encoder forward is chosen from ITS launches' sample spread.  Slot 0 (no bits set) is shared by every caller that names none. */
+#define SEMIDETR_MSDA_POLICY_SLOT(s) (((s) & 0xff) << 8)
+/* The forward kernel is to be a function of the arguments alone: with the adaptive policy WHICH of the two encoder forward
+ * kernels runs depends on when earlier launches' counts reached the host, and the two sum a row's samples in different orders
+ * (results agree to ~2e-6 absolute, not bit for bit) -- two passes over identical inputs may then differ in the last bits,
+ * which the reference's single kernel never does.  With this flag the patch kernel runs (the compiled front end sets it while
+ * torch.use_deterministic_algorithms(True) is in force).  grad_value is accumulated with fp32 atomics either way, exactly as in
+ * the reference (ms_deform_im2col_cuda.cuh:87-159): the BACKWARD's summation order is run-dependent there and here. */
+#define SEMIDETR_MSDA_FIXED_FORWARD 2
 int semidetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                               const int64_t *level_start, const float *sampling_loc,
                               const float *attn_weight, int batch, int spatial_size, int num_heads,
@@ -144,16 +155,23 @@ int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, 
  *                     the region; 10-25 % faster while most samples stay inside, level with the patch kernel when ~70 % of
  *                     them are more than 4 px away (sigma ~5.5 px), slower beyond
  * policy 0 (default, adaptive): both kernels count, in a few workgroups, the share of samples further than 4 px from their
- *   query's pixel centre; launch k's count reaches the host through mapped pinned memory when launch k + 1 starts (no copy
- *   command, no synchronisation) and the NEXT dispatch on that device moves between the kernels with hysteresis (to the
- *   window kernel below 60 %, back above 70 %; five levels 56 % / 66 %).  State is per device; launches inside a stream
- *   capture keep the kernel of the moment and count nothing.
+ *   query's pixel centre; launch k's count reaches the host through mapped pinned memory when launch k + 1 OF THE SAME SLOT starts
+ *   (no copy command, no synchronisation) and the NEXT dispatch of that slot moves between the kernels with hysteresis (to the
+ *   window kernel below 60 %, back above 70 %; five levels 56 % / 66 %).  State is per (device, slot) -- see
+ *   SEMIDETR_MSDA_POLICY_SLOT; launches inside a stream capture keep their slot's kernel of the moment and count nothing.  The
+ *   first adaptive dispatch on a device allocates the counters (64 KB of device memory, 4 KB of pinned host memory; the two
+ *   allocation calls may synchronise that device once).  Launches of ONE slot on two streams of a device at the same time share
+ *   its counter pair: the counts may mix, the results do not depend on them.  The choice makes the forward's last bits depend on
+ *   timing: SEMIDETR_MSDA_FIXED_FORWARD (or policy 1) for bitwise reproducible forwards.
  * policy 1: always the patch kernel.   policy 2: the window kernel whenever it applies.   (Process-wide.)
- * semidetr_msda_forward_policy_state: for the calling thread's current device -- the policy, the kernel the adaptive policy
- *   stands on (0 patch, 1 window), the last far-sample fraction received (-1: none yet), the number of counts received.
+ * If the device does not grant the window kernel its LDS (~150 KB per workgroup) the patch kernel runs instead.
+ * semidetr_msda_forward_policy_state[_slot]: for the calling thread's current device and slot (0 without _slot) -- the policy,
+ *   the kernel the adaptive policy stands on (0 patch, 1 window), the last far-sample fraction received (-1: none yet), the
+ *   number of counts received.
  * ------------------------------------------------------------------------------------------- */
 int semidetr_msda_set_forward_policy(int policy);
 int semidetr_msda_forward_policy_state(int *policy, int *mode, float *far_fraction, unsigned *updates);
+int semidetr_msda_forward_policy_state_slot(int slot, int *policy, int *mode, float *far_fraction, unsigned *updates);
 
 /* Names of the device kernels the LAST semidetr_msda_* call of the calling thread launched ("+"-separated, as the
  * profiler prints their base names), so that a benchmark reports what actually ran instead of a hand-kept table. */

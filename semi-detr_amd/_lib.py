@@ -42,6 +42,7 @@ SIGNATURES = {
     "semidetr_msda_last_kernels": (ctypes.c_char_p, []),
     "semidetr_msda_set_forward_policy": (c_int, [c_int]),
     "semidetr_msda_forward_policy_state": (c_int, [c_void_p] * 4),
+    "semidetr_msda_forward_policy_state_slot": (c_int, [c_int] + [c_void_p] * 4),
     "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
     "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "semidetr_lsap_solve": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 6),
@@ -110,11 +111,12 @@ def set_forward_policy(policy):
     check(lib().semidetr_msda_set_forward_policy(FORWARD_POLICIES.get(policy, policy)), "semidetr_msda_set_forward_policy")
 
 
-def forward_policy_state():
-    """{'policy', 'mode' (0 patch / 1 window), 'far_fraction' (-1: no count received yet), 'updates'} of the current device."""
+def forward_policy_state(slot=0):
+    """{'policy', 'mode' (0 patch / 1 window), 'far_fraction' (-1: no count received yet), 'updates'} of the current device and
+    call-site slot (0 = the slot of callers that name none; MSDeformAttn instances hold theirs in ``policy_slot``)."""
     pol, mode, upd, frac = c_int(), c_int(), ctypes.c_uint(), ctypes.c_float()
-    check(lib().semidetr_msda_forward_policy_state(ctypes.byref(pol), ctypes.byref(mode), ctypes.byref(frac), ctypes.byref(upd)),
-          "semidetr_msda_forward_policy_state")
+    check(lib().semidetr_msda_forward_policy_state_slot(int(slot), ctypes.byref(pol), ctypes.byref(mode), ctypes.byref(frac),
+                                                        ctypes.byref(upd)), "semidetr_msda_forward_policy_state_slot")
     return {"policy": pol.value, "mode": mode.value, "far_fraction": frac.value, "updates": upd.value}
 
 

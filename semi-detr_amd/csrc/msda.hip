@@ -430,22 +430,30 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 constexpr float kFarToWindow = 0.60f;      // patch -> window when fewer than this share of the samples are far ...
 constexpr float kFarToPatch = 0.70f;       // ... window -> patch above this one
 constexpr float kFarToWindow5 = 0.56f, kFarToPatch5 = 0.66f;      // five levels (COCO-Full pyramid: margin 4 instead of 6)
-struct FwdAdapt {
-    unsigned *dev_cnt = nullptr;           // device words: {far, total, kind, -} x launch parity, [8] = publications so far
-    unsigned *pub_host = nullptr;          // mapped pinned memory {sequence, far, total, kind}
-    unsigned *pub_dev = nullptr;           // the same memory as the device sees it
+// Per CALL SITE (round 5): the reference builds twelve MSDeformAttn instances per model (transformer.py:609,760) whose learned offsets
+// reach differently far, so the state is kept per (device, slot): the caller names the slot in bits 8..15 of `flags`
+// (SEMIDETR_MSDA_POLICY_SLOT; the Python module gives every instance its own), slot 0 is the state every caller that names none shares.
+// A slot's counts come from its own launches only and are judged by the thresholds of its own pyramid.
+constexpr int kPolicySlots = 256;
+struct FwdSlot {
     unsigned launches = 0, seen_seq = 0, updates = 0;
     int mode = 0;                          // 0 = patch kernel, 1 = region-window kernel
     float last_frac = -1.f;
+};
+struct FwdAdapt {
+    unsigned *dev_cnt = nullptr;           // device words per slot: {far, total, kind, -} x launch parity, [8] = publications so far
+    unsigned *pub_host = nullptr;          // mapped pinned memory per slot: {sequence, far, total, kind}
+    unsigned *pub_dev = nullptr;           // the same memory as the device sees it
     bool failed = false;                   // allocation failed once: stay with the patch kernel, silently
+    FwdSlot slot[kPolicySlots];
 };
 constexpr int kMaxDevices = 64;
 std::mutex g_adapt_mu;
-FwdAdapt g_adapt[kMaxDevices];
+FwdAdapt *g_adapt[kMaxDevices];            // allocated at a device's first adaptive dispatch
 std::atomic<int> g_fwd_policy{0};          // 0 adaptive, 1 always the patch kernel, 2 the window kernel whenever it applies
 
 // the launch's FwdStats and the kernel to use; called with the stream the launch goes to
-int fwd_adapt_next(hipStream_t st, bool allow_window, int batch, int levels, FwdStats &fs, bool &use_window)
+int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, FwdStats &fs, bool &use_window)
 {
     fs = FwdStats{nullptr, nullptr, nullptr, nullptr};
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
@@ -456,12 +464,15 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int batch, int levels, Fwd
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     std::lock_guard<std::mutex> lock(g_adapt_mu);
-    FwdAdapt &a = g_adapt[dev];
-    if (!a.dev_cnt && !a.failed && !capturing) {       // first use on this device (never inside a stream capture)
+    if (!g_adapt[dev]) g_adapt[dev] = new (std::nothrow) FwdAdapt();
+    if (!g_adapt[dev]) return SEMIDETR_OK;
+    FwdAdapt &a = *g_adapt[dev];
+    if (!a.dev_cnt && !a.failed && !capturing) {       // first use on this device (never inside a stream capture): two small
+        // allocations (these calls may synchronise the device ONCE per process and device) and a clear queued on the launch's stream
         void *h = nullptr, *d = nullptr, *c = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess &&
-            hipMalloc(&c, 64) == hipSuccess && hipMemset(c, 0, 64) == hipSuccess) {
-            std::fill_n(static_cast<unsigned *>(h), 16, 0u);
+        if (hipHostMalloc(&h, kPolicySlots * 16, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess &&
+            hipMalloc(&c, kPolicySlots * 64) == hipSuccess && hipMemsetAsync(c, 0, kPolicySlots * 64, st) == hipSuccess) {
+            std::fill_n(static_cast<unsigned *>(h), kPolicySlots * 4, 0u);
             a.pub_host = static_cast<unsigned *>(h);
             a.pub_dev = static_cast<unsigned *>(d);
             a.dev_cnt = static_cast<unsigned *>(c);
@@ -470,28 +481,30 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int batch, int levels, Fwd
             a.failed = true;
         }
     }
+    FwdSlot &sl = a.slot[slot_id & (kPolicySlots - 1)];
     if (a.dev_cnt) {
-        volatile unsigned *pub = a.pub_host;
+        const int sid = slot_id & (kPolicySlots - 1);
+        volatile unsigned *pub = a.pub_host + 4 * sid;
         const unsigned seq = pub[0];
-        if (seq != a.seen_seq) {                       // a finished launch's counts have arrived since the last look
+        if (seq != sl.seen_seq) {                      // a finished launch's counts have arrived since the last look
             const unsigned far = pub[1], total = pub[2];
             if (pub[0] != seq || far > total) {        // caught between two records (the device writes 16 bytes at once,
                                                        // so this is paranoia): look again at the next dispatch
             } else if (total) {
-                a.seen_seq = seq;
-                a.last_frac = (float)far / (float)total;
-                ++a.updates;
-                if (a.mode == 0 && a.last_frac < (levels == 5 ? kFarToWindow5 : kFarToWindow)) a.mode = 1;
-                else if (a.mode == 1 && a.last_frac > (levels == 5 ? kFarToPatch5 : kFarToPatch)) a.mode = 0;
+                sl.seen_seq = seq;
+                sl.last_frac = (float)far / (float)total;
+                ++sl.updates;
+                if (sl.mode == 0 && sl.last_frac < (levels == 5 ? kFarToWindow5 : kFarToWindow)) sl.mode = 1;
+                else if (sl.mode == 1 && sl.last_frac > (levels == 5 ? kFarToPatch5 : kFarToPatch)) sl.mode = 0;
             }
         }
         if (!capturing) {                              // a captured launch keeps the kernel of the moment and counts nothing
-            const unsigned par = a.launches++ & 1u;
-            fs = FwdStats{a.dev_cnt + 4 * par, a.dev_cnt + 4 * (1 - par), a.pub_dev, a.dev_cnt + 8};
+            const unsigned par = sl.launches++ & 1u;
+            unsigned *base = a.dev_cnt + 16 * sid;
+            fs = FwdStats{base + 4 * par, base + 4 * (1 - par), a.pub_dev + 4 * sid, base + 8};
         }
     }
-    (void)batch;
-    use_window = a.mode == 1;
+    use_window = sl.mode == 1;
     return SEMIDETR_OK;
 }
 
@@ -513,11 +526,14 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
         // encoder self-attention.  The region-window kernel is built for num_point == 4 and four or five levels.  A padding mask
         // (fused prologue; the reference ALWAYS passes one: transformer.py:1309,1460 -> ops/modules/ms_deform_attn.py:95-96) has its
         // own instantiation: padded rows are staged as zeros, level 0 drops padded corners from its records (msda_rw.h).
-        const bool window_ok = P == kPT && (L == 4 || L == 5);
+        // SEMIDETR_MSDA_FIXED_FORWARD: the caller wants the kernel to be a function of the arguments alone (bitwise reproducible
+        // forward: the two kernels sum in different orders) -- the patch kernel, whatever the policy says.
+        const bool window_ok = P == kPT && (L == 4 || L == 5) && !(flags & SEMIDETR_MSDA_FIXED_FORWARD);
         FwdStats fs;
         bool use_window = false;
-        if (int rc = fwd_adapt_next(st, window_ok, N, L, fs, use_window)) return rc;
+        if (int rc = fwd_adapt_next(st, window_ok, (flags >> 8) & 0xff, L, fs, use_window)) return rc;
         if (use_window) {
+            bool fell_back = false;      // a device / runtime that does not grant the window kernel its ~150 KB of LDS gets the patch kernel, not an error
             // level 0 through global loads, windows of the coarse levels with the widest margin that fits beside the
             // octet records: one workgroup per CU either way, and the workgroup as large as its registers allow (SEMIDETR_RW_NT).
             //   four levels: 24 x 16 regions, margin FIVE, 113 KB of windows + 34.5 KB of records (16 x 16 regions at margin 4 / 5 / 6 and
@@ -525,7 +541,10 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             //   five levels: 24 x 16 regions, margin FOUR (102 + 53 KB; margin 5 fits only a 640-thread workgroup), 960 threads; patch
             //                kernel 314 / 292 / 299 us at sigma 1 / 2 / 3 px, this one 195 / 204 / 241
             auto launch_window = [&](auto kern, size_t wlds, int threads, int region_px) -> int {
-                if (int rc = allow_big_lds(kern, wlds, "msda_forward")) return rc;
+                if (int rc = allow_big_lds(kern, wlds, "msda_forward")) {      // refused for this instantiation: the patch kernel below
+                    fell_back = true;
+                    return rc;
+                }
                 // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
                 // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
                 const int wbound = ((S * 3 / 4 + region_px - 1) / region_px) * 9 / 8 + 2 * L;
@@ -535,22 +554,28 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
                 g_last_kernels = "msda_rw_d32";
                 return semidetr::launch_status("msda_rw_d32<forward>");
             };
-            constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5>();
-            static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
-            if constexpr (std::is_same<IO, RawIO>::value) {
-                if (io.has_mask()) {
-                    if (L == 4)
-                        return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE, true>,
-                                             wlds4, SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
-                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5, true>, wlds5,
-                                         SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5 * 16);
+            auto pick_window = [&]() -> int {
+                constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5>();
+                static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
+                if constexpr (std::is_same<IO, RawIO>::value) {
+                    if (io.has_mask()) {
+                        if (L == 4)
+                            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE, true>,
+                                                 wlds4, SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
+                        return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5, true>, wlds5,
+                                             SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5 * 16);
+                    }
                 }
-            }
-            if (L == 4)
-                return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4,
-                                     SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
-            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5,
-                                 SEMIDETR_RW_RTH5 * 16);
+                if (L == 4)
+                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4,
+                                         SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
+                return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5,
+                                     SEMIDETR_RW_RTH5 * 16);
+            };
+            const int wrc = pick_window();
+            if (!fell_back) return wrc;
+            (void)hipGetLastError();
+            fs = FwdStats{nullptr, nullptr, nullptr, nullptr};      // (this launch's counter parity was the window kernel's: count nothing)
         }
         // 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges
         // included); a workgroup takes patches slot, slot + hint, ... so any hint >= 1 is correct
@@ -703,18 +728,26 @@ extern "C" int semidetr_msda_set_forward_policy(int policy)
     return SEMIDETR_OK;
 }
 
-extern "C" int semidetr_msda_forward_policy_state(int *policy, int *mode, float *far_fraction, unsigned *updates)
+extern "C" int semidetr_msda_forward_policy_state_slot(int slot, int *policy, int *mode, float *far_fraction, unsigned *updates)
 {
+    SEMIDETR_REQUIRE(slot >= 0 && slot < kPolicySlots, SEMIDETR_E_BADARG, "msda_forward_policy_state: slot must be 0..%d", kPolicySlots - 1);
     int dev = 0;
     const hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return semidetr::fail((int)e, "msda_forward_policy_state: %s", hipGetErrorString(e));
     std::lock_guard<std::mutex> lock(g_adapt_mu);
-    const FwdAdapt &a = g_adapt[dev >= 0 && dev < kMaxDevices ? dev : 0];
+    const FwdAdapt *a = g_adapt[dev >= 0 && dev < kMaxDevices ? dev : 0];
+    const FwdSlot none;
+    const FwdSlot &sl = a ? a->slot[slot] : none;
     if (policy) *policy = g_fwd_policy.load(std::memory_order_relaxed);
-    if (mode) *mode = a.mode;
-    if (far_fraction) *far_fraction = a.last_frac;
-    if (updates) *updates = a.updates;
+    if (mode) *mode = sl.mode;
+    if (far_fraction) *far_fraction = sl.last_frac;
+    if (updates) *updates = sl.updates;
     return SEMIDETR_OK;
+}
+
+extern "C" int semidetr_msda_forward_policy_state(int *policy, int *mode, float *far_fraction, unsigned *updates)
+{
+    return semidetr_msda_forward_policy_state_slot(0, policy, mode, far_fraction, updates);
 }
 
 #if SEMIDETR_EXPERIMENTS

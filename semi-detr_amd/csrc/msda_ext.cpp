@@ -136,16 +136,21 @@ int pyramid_check(const at::Tensor &shapes, const at::Tensor &starts, int64_t S)
     return result;
 }
 
-int self_attention_flags(const at::Tensor &shapes, const at::Tensor &starts, int Lq, int S)
+// `flags` of the f32 entry points: the self-attention statement, the call site's slot of the forward-kernel choice, and -- while
+// torch.use_deterministic_algorithms(True) is in force -- a forward kernel that does not depend on earlier launches
+int self_attention_flags(const at::Tensor &shapes, const at::Tensor &starts, int Lq, int S, int64_t policy_slot = 0)
 {
-    return (Lq == S && (pyramid_check(shapes, starts, S) & 2)) ? SEMIDETR_MSDA_QUERIES_ARE_PIXELS : 0;
+    TORCH_CHECK(policy_slot >= 0 && policy_slot <= 255, "policy_slot must be 0..255, got ", policy_slot);
+    return ((Lq == S && (pyramid_check(shapes, starts, S) & 2)) ? SEMIDETR_MSDA_QUERIES_ARE_PIXELS : 0) |
+           SEMIDETR_MSDA_POLICY_SLOT((int)policy_slot) |
+           (at::globalContext().deterministicAlgorithms() ? SEMIDETR_MSDA_FIXED_FORWARD : 0);
 }
 
 void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 at::Tensor ms_deform_attn_forward(const at::Tensor &value, const at::Tensor &spatial_shapes,
                                   const at::Tensor &level_start_index, const at::Tensor &sampling_loc,
-                                  const at::Tensor &attn_weight, int64_t im2col_step)
+                                  const at::Tensor &attn_weight, int64_t im2col_step, int64_t policy_slot)
 {
     const Dims d = op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
                            "ms_deform_attn_forward_cuda");
@@ -161,7 +166,7 @@ at::Tensor ms_deform_attn_forward(const at::Tensor &value, const at::Tensor &spa
     else
         rc = semidetr_msda_forward_f32(stream_of(value), value.data_ptr<float>(), sh, ls, sampling_loc.data_ptr<float>(),
                                        attn_weight.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
-                                       self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S),
+                                       self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S, policy_slot),
                                        out.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_forward");
     return out;
@@ -316,7 +321,7 @@ at::Tensor mask_extents(const at::Tensor &m, const at::Tensor &shapes, const at:
 at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tensor &spatial_shapes,
                                         const at::Tensor &level_start_index, const at::Tensor &reference_points,
                                         const at::Tensor &sampling_offsets, const at::Tensor &attn_logits,
-                                        const c10::optional<at::Tensor> &padding_mask)
+                                        const c10::optional<at::Tensor> &padding_mask, int64_t policy_slot)
 {
     const Dims d = fused_dims(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits);
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
@@ -330,7 +335,7 @@ at::Tensor ms_deform_attn_fused_forward(const at::Tensor &value, const at::Tenso
         stream_of(value), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(), level_start_index.data_ptr<int64_t>(),
         ref.data_ptr<float>(), (int)reference_points.size(-1), sampling_offsets.data_ptr<float>(),
         attn_logits.data_ptr<float>(), mask, mask ? ext.data_ptr<int>() : nullptr, d.N, d.S, d.M, d.D, d.L, d.Lq, d.P,
-        self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), out.data_ptr<float>());
+        self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S, policy_slot), out.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_fused_forward");
     return out;
 }
@@ -369,12 +374,15 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "MultiScaleDeformableAttention for MI355X (gfx950): at::Tensor front end of libsemidetr_hip.so";
     // the reference's surface (src/vision.cpp:13-16)
-    m.def("ms_deform_attn_forward", &ms_deform_attn_forward, "ms_deform_attn_forward");
+    // (+ an optional trailing `policy_slot`: the call site's slot of the encoder forward-kernel choice, semidetr_hip.h)
+    m.def("ms_deform_attn_forward", &ms_deform_attn_forward, "ms_deform_attn_forward", py::arg("value"), py::arg("spatial_shapes"),
+          py::arg("level_start_index"), py::arg("sampling_loc"), py::arg("attn_weight"), py::arg("im2col_step"),
+          py::arg("policy_slot") = 0);
     m.def("ms_deform_attn_backward", &ms_deform_attn_backward, "ms_deform_attn_backward");
     // additions
     m.def("ms_deform_attn_fused_forward", &ms_deform_attn_fused_forward, py::arg("value"), py::arg("spatial_shapes"),
           py::arg("level_start_index"), py::arg("reference_points"), py::arg("sampling_offsets"), py::arg("attn_logits"),
-          py::arg("padding_mask") = py::none());
+          py::arg("padding_mask") = py::none(), py::arg("policy_slot") = 0);
     m.def("ms_deform_attn_fused_backward", &ms_deform_attn_fused_backward, py::arg("value"), py::arg("spatial_shapes"),
           py::arg("level_start_index"), py::arg("reference_points"), py::arg("sampling_offsets"), py::arg("attn_logits"),
           py::arg("grad_output"), py::arg("padding_mask") = py::none());

@@ -18,10 +18,11 @@ from ... import MultiScaleDeformableAttention as MSDA
 class MSDeformAttnFunction(Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
-                attention_weights, im2col_step):
+                attention_weights, im2col_step, policy_slot=0):
+        # policy_slot (optional, not in the reference's signature): the call site's slot of the encoder forward-kernel choice
         ctx.im2col_step = im2col_step
         output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
-                                             sampling_locations, attention_weights, ctx.im2col_step)
+                                             sampling_locations, attention_weights, ctx.im2col_step, policy_slot)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                               attention_weights)
         return output
@@ -33,24 +34,24 @@ class MSDeformAttnFunction(Function):
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
             grad_output.contiguous(), ctx.im2col_step)
-        return grad_value, None, None, grad_sampling_loc, grad_attn_weight, None
+        return (grad_value, None, None, grad_sampling_loc, grad_attn_weight, None, None)[:len(ctx.needs_input_grad)]
 
 
 class MSDeformAttnFusedFunction(Function):
     """MSDeformAttn.forward between the Linear layers as ONE op: consumes the
     reference points, the raw sampling offsets and the raw attention logits; softmax, location arithmetic
     (detr_od/models/utils/ops/modules/ms_deform_attn.py:99-111) and their backward run inside the gfx950 kernels.
-    ``apply(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits[, padding_mask])``.
+    ``apply(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits[, padding_mask[, policy_slot]])``.
     ``padding_mask`` (N, S) bool, True = padding: ``value.masked_fill(mask[..., None], 0)`` (ms_deform_attn.py:95-96) folded
     into the kernels -- pass the UNMASKED value; its gradient comes back with zero rows at the padded pixels."""
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits,
-                padding_mask=None):
+                padding_mask=None, policy_slot=0):
         if padding_mask is not None:
             padding_mask = padding_mask.contiguous()
         output = MSDA.ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points,
-                                                   sampling_offsets, attn_logits, padding_mask)
+                                                   sampling_offsets, attn_logits, padding_mask, policy_slot)
         ctx.save_for_backward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
                               attn_logits, padding_mask)
         return output
@@ -73,4 +74,4 @@ class MSDeformAttnFusedFunction(Function):
                 scale = 0.5 * wh / P
                 grad_loc = torch.where(scale != 0, grad_off / scale, torch.zeros_like(grad_off))
                 grad_ref = torch.cat([grad_loc.sum((2, 4)), (grad_loc * off * (0.5 / P)).sum((2, 4))], -1)
-        return grad_value, None, None, grad_ref, grad_off, grad_logits, None
+        return (grad_value, None, None, grad_ref, grad_off, grad_logits, None, None)[:len(ctx.needs_input_grad)]

@@ -7,6 +7,7 @@ initialisation (:62-76), same ``forward`` arguments, errors and arithmetic (:78-
 layers are dense GEMMs and stay on hipBLASLt/MFMA through torch; the sampling + aggregation and its
 gradient go through ``MSDeformAttnFunction`` to the hand-written gfx950 kernels.
 """
+import itertools
 import math
 import warnings
 
@@ -24,6 +25,9 @@ def _is_power_of_2(n):
     return n != 0 and (n & (n - 1)) == 0
 
 
+_policy_slots = itertools.count(1)
+
+
 class MSDeformAttn(nn.Module):
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
@@ -39,6 +43,10 @@ class MSDeformAttn(nn.Module):
         # intermediates in HBM.  Not a parameter / buffer -> state_dict is unchanged.  Set False for the
         # reference's op-by-op sequence.
         self.fuse_prologue = True
+        # Which of the two encoder forward kernels runs follows how far THIS instance's learned offsets reach (semidetr_hip.h:
+        # SEMIDETR_MSDA_POLICY_SLOT): instances take consecutive slots 1..255 (the reference builds 12 per model,
+        # transformer.py:609,760; beyond 255 instances slots are shared, which only mixes their counts).  Plain attribute.
+        self.policy_slot = (next(_policy_slots) - 1) % 255 + 1
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
 
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
@@ -89,7 +97,8 @@ class MSDeformAttn(nn.Module):
             # gradient
             output = MSDeformAttnFusedFunction.apply(value.contiguous(), input_spatial_shapes,
                                                      input_level_start_index, reference_points.contiguous(),
-                                                     offsets.contiguous(), logits.contiguous(), input_padding_mask)
+                                                     offsets.contiguous(), logits.contiguous(), input_padding_mask,
+                                                     self.policy_slot)
             return self.output_proj(output)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None, None], float(0))
@@ -106,8 +115,8 @@ class MSDeformAttn(nn.Module):
 
         if value.dtype == torch.float16:      # amp: the op itself runs in fp32 (ms_deform_attn.py:114-120)
             output = MSDeformAttnFunction.apply(value.float(), input_spatial_shapes, input_level_start_index,
-                                                locations.float(), weights.float(), self.im2col_step)
+                                                locations.float(), weights.float(), self.im2col_step, self.policy_slot)
             return self.output_proj(output.to(torch.float16))
         output = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
-                                            locations.contiguous(), weights.contiguous(), self.im2col_step)
+                                            locations.contiguous(), weights.contiguous(), self.im2col_step, self.policy_slot)
         return self.output_proj(output)

@@ -274,6 +274,69 @@ def test_adaptive_policy_follows_the_sample_spread():
     assert k_far[0] == "msda_rw_d32" and k_far[-1] == "msda_fwd_d32<1, 4, 408", k_far
 
 
+def test_adaptive_policy_is_kept_per_call_site():
+    """Two "layers" whose offsets reach differently far (sigma 1 px and 7 px), called alternately as the layers of an encoder are
+    (the reference builds twelve MSDeformAttn instances per model, transformer.py:609,760): with a slot each
+    (SEMIDETR_MSDA_POLICY_SLOT, the module's `policy_slot`) each settles on ITS kernel and stays there, whatever the other one
+    does; the shared slot 0 is not touched.  Results equal the oracle's throughout."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd as sda
+    sda._lib.set_forward_policy("adaptive")
+    shapes = [(40, 54), (20, 27), (10, 14), (5, 7)]
+    shp = np.asarray(shapes, np.int64)
+    tsh = _t(shp)
+    tls = _starts(tsh)
+    layers = {}
+    for slot, sigma in ((7, 1.0), (8, 7.0)):
+        value, _, ref, off, logits, _ = _encoder_case(2, shapes, sigma, 40 + slot)
+        loc, attn = _prologue_np(ref, off, logits, shp, P)
+        layers[slot] = ((_t(value), tsh, tls, _t(loc), _t(attn), 64, slot), oracle.msda_forward(value, shp, loc, attn))
+    before0 = sda._lib.forward_policy_state(0)["updates"]
+    seen = {7: [], 8: []}
+    for it in range(10):
+        for slot, (a, want) in layers.items():
+            out = MSDA.ms_deform_attn_forward(*a)
+            seen[slot].append(_last())
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6)
+    st7, st8 = sda._lib.forward_policy_state(7), sda._lib.forward_policy_state(8)
+    assert st7["mode"] == 1 and st7["far_fraction"] < 0.60 and st7["updates"] >= 5, st7
+    assert st8["mode"] == 0 and st8["far_fraction"] > 0.70 and st8["updates"] >= 5, st8
+    assert set(seen[7][4:]) == {"msda_rw_d32"}, seen[7]                 # settled after a few launches, then never moved
+    assert set(seen[8]) == {"msda_fwd_d32<1, 4, 408"}, seen[8]
+    assert sda._lib.forward_policy_state(0)["updates"] == before0
+    # the nn.Module: every instance takes its own slot
+    from semi_detr_amd import MSDeformAttn
+    a, b = MSDeformAttn(), MSDeformAttn()
+    assert 1 <= a.policy_slot <= 255 and b.policy_slot == a.policy_slot % 255 + 1
+
+
+def test_deterministic_algorithms_pin_the_forward_kernel():
+    """torch.use_deterministic_algorithms(True): the front end asks for a forward kernel that does not depend on earlier launches
+    (SEMIDETR_MSDA_FIXED_FORWARD) -- the patch kernel even under policy "window", and two passes over the same inputs
+    agree bit for bit, as the reference's single kernel does."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd as sda
+    value, shp, loc, attn = _case([(40, 54), (20, 27), (10, 14), (5, 7)], 2, "near", 77)
+    tsh = _t(shp)
+    a = (_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)
+    sda._lib.set_forward_policy("window")
+    o_win = MSDA.ms_deform_attn_forward(*a)
+    assert _last() == "msda_rw_d32"
+    torch.use_deterministic_algorithms(True)
+    try:
+        o1 = MSDA.ms_deform_attn_forward(*a)
+        assert _last() == "msda_fwd_d32<1, 4, 408", _last()
+        sda._lib.set_forward_policy("adaptive")
+        outs = [MSDA.ms_deform_attn_forward(*a) for _ in range(6)]
+        assert _last() == "msda_fwd_d32<1, 4, 408", _last()
+    finally:
+        torch.use_deterministic_algorithms(False)
+    for o in outs:
+        assert torch.equal(o, o1)
+    np.testing.assert_allclose(o_win.cpu().numpy(), o1.cpu().numpy(), rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("policy", ["window", "adaptive"])
 def test_forward_inside_a_stream_capture(policy):
     """The encoder forward captured into a HIP graph and replayed: the dispatcher must not allocate, copy or synchronise while
