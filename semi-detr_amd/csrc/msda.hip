@@ -66,6 +66,13 @@ constexpr int kMaxLevels = 32;
 #ifndef SEMIDETR_SCATTER_NT
 #define SEMIDETR_SCATTER_NT 512    // (704 threads = one sample per thread, no half-empty second sample slot, two workgroups per CU:
 #endif                             //  encoder backward 726 against 678 us at bs 4 -- the third workgroup is worth more)
+#ifndef SEMIDETR_GW_NT           // msda_gw_d32 (lane-per-sample gather of the encoder backward): threads, region, margins of level 0 / the coarse levels
+#define SEMIDETR_GW_NT 768
+#define SEMIDETR_GW_RTH 16
+#define SEMIDETR_GW_RTW 16
+#define SEMIDETR_GW_H0 4
+#define SEMIDETR_GW_HC 4
+#endif
 #ifndef SEMIDETR_RW_NT
 #define SEMIDETR_RW_NT 768       // msda_rw_d32: threads per workgroup.  Its windows take most of the LDS, so a CU holds ONE workgroup and
                                  // the workgroup's size is the CU's occupancy: 12 instead of 8 waves 192.9 -> 176.7 us inside the step
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 #endif
 #include "msda_region.h" // region-owned windowed scatter for encoder self-attention
 #include "msda_rw.h"     // region-window forward (product since round 4) / gather (experiments) for encoder self-attention
+#include "msda_gw.h"     // lane-per-sample region-window gather for the encoder backward (round 5)
 #if SEMIDETR_EXPERIMENTS    // negative results kept as evidence: only in libsemidetr_hip_exp.so
 #include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
 #include "msda_lw.h"     // LDS-window forward for encoder self-attention
@@ -508,6 +516,18 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, F
     return SEMIDETR_OK;
 }
 
+// what the slot's forward choice says about its samples, for the BACKWARD's gather (same data, one forward earlier): true = they stay
+// near their queries (the window kernels pay).  Reads the state, counts nothing.
+bool slot_samples_are_near(int slot_id)
+{
+    const int policy = g_fwd_policy.load(std::memory_order_relaxed);
+    if (policy != 0) return policy == 2;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+    std::lock_guard<std::mutex> lock(g_adapt_mu);
+    return g_adapt[dev] && g_adapt[dev]->slot[slot_id & (kPolicySlots - 1)].mode == 1;
+}
+
 // ---- product dispatch of the fast path (fp32, channels == 32), shared by the reference contract (LocAttnIO) and the
 //      fused prologue (RawIO).  Apart from the forward-kernel choice above, what runs is a function of the arguments only.
 template <typename IO>
@@ -625,7 +645,30 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         const int gt = (Lq + 31) / 32;
         SEMIDETR_REQUIRE((int64_t)N * std::max(gbound, gt) * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
         float4 *zero = fill_in_gather ? reinterpret_cast<float4 *>(grad_value) : nullptr;
-        if (L * P == 16)             // DINO: sample loop unrolled, results in registers
+        bool window_gather = false;
+        if (L == 4 && P == kPT && fill_in_gather && slot_samples_are_near((flags >> 8) & 0xff)) {
+            // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
+            auto launch_gw = [&](auto kern) -> bool {
+                constexpr size_t wl = gw_lds_bytes<SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();
+                if (allow_big_lds(kern, wl, "msda_backward") != SEMIDETR_OK) {      // refused: the patch gather below
+                    (void)hipGetLastError();
+                    return false;
+                }
+                const int wbound = ((S * 3 / 4 + SEMIDETR_GW_RTH * SEMIDETR_GW_RTW - 1) / (SEMIDETR_GW_RTH * SEMIDETR_GW_RTW)) * 9 / 8 + 2 * L;
+                if ((int64_t)N * wbound * M >= INT32_MAX) return false;
+                hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(SEMIDETR_GW_NT), wl, st, grad_out, value, spatial_shapes,
+                                   level_start, io, S, M, wbound, zero, (int64_t)(fill / 16));
+                return true;
+            };
+            if constexpr (std::is_same<IO, RawIO>::value) {
+                if (io.has_mask())
+                    window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, true>);
+            }
+            if (!window_gather && !io.has_mask())
+                window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false>);
+        }
+        if (window_gather) {
+        } else if (L * P == 16)             // DINO: sample loop unrolled, results in registers
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 16, 408, SEMIDETR_GATHER_WPE, SEMIDETR_GATHER_KB>), dim3((unsigned)((int64_t)N * gbound * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gbound, zero, (int64_t)(fill / 16));
         else if (L * P == 20)        // five levels (COCO-Full recipe)
@@ -639,7 +682,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         else
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
-        if (int rc = semidetr::launch_status("msda_bwd_gather_d32")) return rc;
+        if (int rc = semidetr::launch_status(window_gather ? "msda_gw_d32" : "msda_bwd_gather_d32")) return rc;
         auto kern = &msda_bwd_scatter_d32_reg<IO, SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 8, 16, 24, 32, 0, SEMIDETR_SCATTER_WPE, SEMIDETR_SCATTER_WU>;
         const size_t rlds = reg_lds_bytes<SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 24, 32>();
         if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
@@ -648,8 +691,9 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
         hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(SEMIDETR_SCATTER_NT), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L,
                            rbound, grad_value);
-        g_last_kernels = fill_in_gather ? "msda_bwd_gather_d32+msda_bwd_scatter_d32_reg"
-                                        : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg";
+        g_last_kernels = window_gather ? "msda_gw_d32+msda_bwd_scatter_d32_reg"
+                         : (fill_in_gather ? "msda_bwd_gather_d32+msda_bwd_scatter_d32_reg"
+                                           : "fillBufferAligned+msda_bwd_gather_d32+msda_bwd_scatter_d32_reg");
         return semidetr::launch_status("msda_bwd_scatter_d32_reg");
     }
     // ---- any query set

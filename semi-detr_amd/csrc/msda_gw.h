@@ -1,0 +1,303 @@
+// Gather half of the encoder self-attention BACKWARD with ONE LANE PER SAMPLE on region windows in LDS (fp32, D == 32,
+// num_point == 4, four levels: L * P == 16 samples per (query, head) = one DPP row): grad_sampling_loc / grad_attn_weight
+// (ms_deform_im2col_cuda.cuh:87-159, :301-403), optionally clearing grad_value for the scatter launch that follows.
+// Included by msda.hip after msda_rw.h (window geometry RwWin, rw_first).  Round 5.
+//
+// Why.  The patch gather (msda_bwd_gather_d32) pulls 4 x 128 B per sample through the vector-memory path (5.8 GB per bs-4 launch
+// at 64 B/clk/CU: 282 us, TA-bound like the patch forward); the region-window gather of round 4 (msda_rw_d32<GATHER>) moved the
+// rows into LDS but kept the forward's layout -- 8 lanes x float4 per row, so each of a sample's four dot products <grad_out,
+// corner row> is spread over 8 lanes and costs a DPP reduction: ~53 lane-instructions per sample and lane, VALU-bound at 325-342 us.
+// Here a lane owns a sample: it holds its query's 32 grad_out channels in registers, reads its four corner rows completely
+// (4 x 8 ds_read_b128) and forms the four dots in-lane with packed FMAs -- no cross-lane step at all, ~3.5 wave-instructions per
+// sample instead of ~7.  Sixteen consecutive lanes = the 16 samples of one (query, head) row = one DPP row, so the fused prologue's
+// softmax and the softmax backward's row sum are 4-step DPP reductions.
+//   * windows of ALL levels in LDS (a lane cannot fetch a row from global memory without 32 uncoalesced loads): regions of
+//     RTH x RTW pixels of the finest level, margins H0 / HC (RwWin, msda_rw.h), staged exactly like the forward's; rows outside
+//     a level (and padded rows, MASK) are zeros, which IS the op's zero padding -- the dots need no corner validity;
+//   * bank conflicts: ds_read_b128 is served in four groups of 16 lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32)
+//     (MI355X_MICROARCH.md, LDS table); a 128-byte row covers half of the 64 banks.  A lane's position g in its group (0..15) gives it
+//     a chunk swizzle j = g & 7 -- it reads the eight 16-byte chunks of a row in the order c ^ j, and holds grad_out in the same
+//     order -- and a parity class g >> 3: window widths are odd, so a sample's four rows are two of each parity, and class-0 lanes
+//     read them in the order even, odd, odd, even, class-1 lanes odd, even, even, odd.  The 16 lanes of a group then hit 16 distinct
+//     (parity, chunk) = all 64 banks at every step: conflict-free by construction;
+//   * a sample whose footprint leaves its window is handled by the WHOLE wave afterwards (rare while the offsets stay near the
+//     queries): lane -> (corner, 8-byte piece) loads the four rows coalesced, multiplies with the query's grad_out piece, a DPP row
+//     sum per corner, the owner takes the four dots.  Any input is correct; locality only decides speed (the dispatcher takes the
+//     patch gather when the slot's forward policy says the samples are far, msda.hip).
+#pragma once
+
+template <int RTH, int RTW, int H0, int HC, int KL>
+constexpr size_t gw_lds_bytes() { return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128; }
+
+template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool MASK = false, int DBG = 0>
+__global__ __launch_bounds__(NT, 1) void msda_gw_d32(
+    const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ starts, const IO io, int S, int M, int regions_bound, float4 *__restrict__ zero, int64_t zero_n4)
+{
+    io.same_dims(S, M, KL);
+    using Wn = RwWin<RTH, RTW, H0, HC, KL>;
+    constexpr int P = kPT, LP = KL * P, QPR = NT / LP;      // queries per round
+    static_assert(H0 >= 0 && LP == 16, "every level has a window; the 16 samples of a (query, head) row fill one DPP row");
+    static_assert(Wn::total * 128 <= 160 * 1024, "windows do not fit the LDS");
+    constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
+
+    extern __shared__ float4 smem[];
+    char *const lds = reinterpret_cast<char *>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = tid & (LP - 1), lvl = k / P;            // my sample of the row, its level
+    const int Lq = S, rs = M * kD;
+    const int b = (int)blockIdx.x;
+    const int m = (b % M + (b / M) / kRwHeadRun) % M;
+    const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
+
+    if (zero) {      // side job: clear grad_value, which the scatter launch that FOLLOWS accumulates into
+        const int64_t per = (zero_n4 + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < zero_n4 ? lo + per : zero_n4;
+        for (int64_t i = lo + tid; i < hi; i += NT) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    // per-level data in lanes 0 .. KL-1 of every wave (as msda_rw_d32): wave-uniform copies by readlane, per-lane ones by __shfl
+    const int r_H = lane < KL ? (int)shapes[2 * lane] : 1, r_W = lane < KL ? (int)shapes[2 * lane + 1] : 1;
+    const int r_st = lane < KL ? (int)starts[lane] : 0;
+    int r_wh = 1, r_ww = 1;
+#pragma unroll
+    for (int l = 0; l < KL; ++l)
+        if (lane == l) { r_wh = Wn::wh(l); r_ww = Wn::ww(l); }
+    int Hs[KL], Ws[KL], sts[KL];
+#pragma unroll
+    for (int l = 0; l < KL; ++l) {
+        Hs[l] = __builtin_amdgcn_readlane(r_H, l);
+        Ws[l] = __builtin_amdgcn_readlane(r_W, l);
+        sts[l] = __builtin_amdgcn_readlane(r_st, l);
+    }
+    // my sample's level: sizes and window geometry
+    const int myH = __shfl(r_H, lvl, 64), myW = __shfl(r_W, lvl, 64), myst = __shfl(r_st, lvl, 64);
+    int my_wh1 = 0, my_ww = 1, my_row0 = 0;
+#pragma unroll
+    for (int l = 0; l < KL; ++l)
+        if (lvl == l) { my_wh1 = Wn::wh(l) - 1; my_ww = Wn::ww(l); my_row0 = Wn::row0(l); }
+    // padding mask: every level's summary (MaskExt) as a wave-uniform word
+    int ves[KL];
+#pragma unroll
+    for (int l = 0; l < KL; ++l) ves[l] = -1;
+    if constexpr (MASK) {
+        const int r_ve = lane < KL ? io.mask_ext(n, lane).ve : -1;
+#pragma unroll
+        for (int l = 0; l < KL; ++l) ves[l] = __builtin_amdgcn_readlane(r_ve, l);
+    }
+    // position in my ds_read_b128 lane group -> chunk swizzle and parity class (see the header)
+    const int l5 = lane & 31;
+    const int g = l5 < 4 ? l5 : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : (l5 < 28 ? l5 - 12 : l5 - 16)));
+    const unsigned jj = (unsigned)(g & 7) << 4;           // byte offset of the chunk I read first
+    const int cls = g >> 3;
+
+    const int Hb = Hs[0], Wb = Ws[0];                     // the region grid lives on level 0
+    const int nry = (Hb + RTH - 1) / RTH, nrx = (Wb + RTW - 1) / RTW, nregions = nry * nrx;
+    const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)n * S * M * kD, (unsigned)S * M * kD * 4u);
+    const __amdgpu_buffer_rsrc_t gr = image_rsrc(gout + (int64_t)n * Lq * M * kD, (unsigned)Lq * M * kD * 4u);
+    const unsigned row_bytes = (unsigned)rs * 4u, head_b = (unsigned)(m * kD) * 4u;
+
+    for (int reg = slot0; reg < nregions; reg += regions_bound) {
+        // balanced tiling of the region grid (msda_rw_d32): heights / widths differ by at most one, none exceeds RTH / RTW
+        const int ry_b = reg / nrx, rx_b = reg - ry_b * nrx;
+        const int y0b = (ry_b * Hb) / nry, y1b = ((ry_b + 1) * Hb) / nry;
+        const int x0b = (rx_b * Wb) / nrx, x1b = ((rx_b + 1) * Wb) / nrx;
+        // the region's queries: on every level an exact rectangle; window origins: where the region centre maps to, minus half the window
+        int r_ylo = 0, r_xlo = 0, r_w = 1, r_cnt = 0;
+        float r_invw = 1.f;
+        const float pcy = 0.5f * (float)(y0b + y1b) / (float)Hb, pcx = 0.5f * (float)(x0b + x1b) / (float)Wb;
+        const int r_wy0 = (int)floorf(pcy * (float)r_H - 0.5f) - r_wh / 2 + 1;
+        const int r_wx0 = (int)floorf(pcx * (float)r_W - 0.5f) - r_ww / 2 + 1;
+        if (lane < KL) {
+            const int ylo_ = rw_first(y0b, r_H, Hb), yhi_ = y1b >= Hb ? r_H : rw_first(y1b, r_H, Hb);
+            const int xlo_ = rw_first(x0b, r_W, Wb), xhi_ = x1b >= Wb ? r_W : rw_first(x1b, r_W, Wb);
+            r_ylo = ylo_;
+            r_xlo = xlo_;
+            r_w = max(xhi_ - xlo_, 1);
+            r_cnt = max(yhi_ - ylo_, 0) * max(xhi_ - xlo_, 0);
+            r_invw = 1.f / (float)r_w;
+        }
+        int cnt[KL], wy0[KL], wx0[KL], nq_total = 0;
+#pragma unroll
+        for (int l = 0; l < KL; ++l) {
+            cnt[l] = __builtin_amdgcn_readlane(r_cnt, l);
+            wy0[l] = __builtin_amdgcn_readlane(r_wy0, l);
+            wx0[l] = __builtin_amdgcn_readlane(r_wx0, l);
+            nq_total += cnt[l];
+        }
+        const int my_wy0 = __shfl(r_wy0, lvl, 64), my_wx0 = __shfl(r_wx0, lvl, 64);
+        auto slot_query = [&](int s) -> int {      // s-th query of the region (levels in order) or -1
+            const bool ok = s < nq_total;
+            int lq = 0;
+#pragma unroll
+            for (int l = 0; l < KL - 1; ++l)
+                if (lq == l && s >= cnt[l]) { s -= cnt[l]; lq = l + 1; }
+            const int yl = __shfl(r_ylo, lq, 64), xl = __shfl(r_xlo, lq, 64), w_ = __shfl(r_w, lq, 64);
+            const int st_ = __shfl(r_st, lq, 64), W_ = __shfl(r_W, lq, 64);
+            const int dy = (int)(((float)s + 0.5f) * __shfl(r_invw, lq, 64));      // s / w_ (s < 2^15: exact)
+            return ok ? st_ + (yl + dy) * W_ + xl + (s - dy * w_) : -1;
+        };
+
+        // ---- stage the windows through registers: all loads of a thread first, then its stores (as msda_rw_d32)
+        {
+            constexpr int RPS = NT / 8;
+            constexpr int kMaxSteps = (Wn::zrow + RPS - 1) / RPS + KL;
+            float4 sv[kMaxSteps];
+            unsigned smk[MASK ? kMaxSteps : 1];
+            const unsigned char *mask_n = nullptr;
+            if constexpr (MASK) mask_n = io.mask + (int64_t)n * S;
+            const int ocs = tid >> 3, j8s = tid & 7;
+            const unsigned lane_bs = head_b + (unsigned)j8s * 16u;
+            int nst = 0;
+#pragma unroll
+            for (int l = 0; l < KL; ++l) {
+                const int ww_ = Wn::ww(l), rows_ = Wn::rows(l);
+                int r = ocs, wy = ocs / ww_, wx = ocs - wy * ww_;
+#pragma unroll
+                for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
+                    const int py = wy0[l] + wy, px = wx0[l] + wx;
+                    const bool ok = r < rows_ && (unsigned)py < (unsigned)Hs[l] && (unsigned)px < (unsigned)Ws[l];
+                    const unsigned goff = ok ? (unsigned)(sts[l] + py * Ws[l] + px) * row_bytes + lane_bs : kOob;
+                    if constexpr (MASK) {
+                        smk[nst] = 0u;
+                        if (ves[l] < 0) smk[nst] = mask_n[ok ? sts[l] + py * Ws[l] + px : 0];
+                    }
+                    sv[nst++] = buf_ld4(vr, goff);
+                    r += RPS;
+                    wx += RPS % ww_;
+                    wy += RPS / ww_;
+                    if (wx >= ww_) { wx -= ww_; ++wy; }
+                }
+            }
+            __syncthreads();               // every wave is done with the previous region's windows
+            int ist = 0;
+#pragma unroll
+            for (int l = 0; l < KL; ++l) {
+                const int ww_ = Wn::ww(l), rows_ = Wn::rows(l);
+                int r = ocs, wy = ocs / ww_, wx = ocs - wy * ww_;
+                const int vh_l = ves[l] & 0xffff, vw_l = (int)((unsigned)ves[l] >> 16);
+                (void)wy; (void)wx; (void)vh_l; (void)vw_l;
+#pragma unroll
+                for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
+                    if constexpr (MASK) {      // a padded pixel's row is staged as zeros: value.masked_fill(mask, 0)
+                        const bool pad = ves[l] >= 0 ? (wy0[l] + wy >= vh_l || wx0[l] + wx >= vw_l) : smk[ist] != 0;
+                        if (pad) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        wx += RPS % ww_;
+                        wy += RPS / ww_;
+                        if (wx >= ww_) { wx -= ww_; ++wy; }
+                    }
+                    if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8s * 16) = sv[ist];
+                    ++ist;
+                    r += RPS;
+                }
+            }
+            if (ocs < Wn::zrows) *reinterpret_cast<float4 *>(lds + kZ0 + ocs * 128 + j8s * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();                   // the windows are complete
+
+        const int nrounds = (nq_total + QPR - 1) / QPR;
+        for (int round = 0; round < nrounds; ++round) {
+            const int q = slot_query(round * QPR + (tid >> 4));
+            if (!__any(q >= 0)) break;     // queries are dealt out in order: a wave without one has none later either
+            const bool act = q >= 0;
+            const int qs = act ? q : 0;    // (a lane without a query reads query 0 of the image and stores nothing)
+            const int64_t nq = (int64_t)n * Lq + qs, row = nq * M + m;
+            // ---- my sample's data and my query's grad_out row (chunks in my swizzle order)
+            float x, y;
+            io.load_xy(row, nq, LP, k, lvl, P, myH, myW, x, y);
+            const float raw = io.load_w(row, LP, k);
+            float4 go[8];
+            const unsigned gbase = (unsigned)(qs * M + m) * 128u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) go[c] = buf_ld4(gr, gbase + (((unsigned)c << 4) ^ jj));
+            const float a = row_softmax(io, row, LP, k, raw);      // fused prologue: over the 16 lanes of my DPP row
+
+            // ---- geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 zero padding)
+            const float Hf = (float)myH, Wf = (float)myW;
+            const float h = sub_rn(mul_rn(y, Hf), 0.5f), w = sub_rn(mul_rn(x, Wf), 0.5f);
+            const bool inside = act && h > -1.f && w > -1.f && h < Hf && w < Wf;
+            const float h0f = floorf(h), w0f = floorf(w);
+            // (a NaN location must not leak through 0 * NaN: fractions are zero unless the sample counts)
+            const float lh = inside ? sub_rn(h, h0f) : 0.f, lw = inside ? sub_rn(w, w0f) : 0.f;
+            const int wy = (int)h0f - my_wy0, wx = (int)w0f - my_wx0;
+            const bool inwin = inside && (unsigned)wy < (unsigned)my_wh1 && (unsigned)wx < (unsigned)(my_ww - 1);
+            const bool far = inside && !inwin;
+            const int rl = my_row0 + wy * my_ww + wx;      // window row of the top-left corner
+            const int sw = (rl ^ cls) & 1;                 // reading order: column sw first (parity of the row ^ my class)
+            // (top, sw), (top, !sw), (bottom, sw), (bottom, !sw); a sample not served from its window reads the zero rows
+            const unsigned pitch = (unsigned)my_ww * 128u;
+            const unsigned a0 = (inwin ? (unsigned)(rl + sw) * 128u : kZ0 + (unsigned)cls * 128u);
+            const unsigned a1 = (inwin ? (unsigned)(rl + 1 - sw) * 128u : kZ0 + (unsigned)(1 - cls) * 128u);
+            const unsigned a2 = a0 + pitch, a3 = a1 + pitch;
+
+            // ---- four dots <grad_out, corner row>, 16 bytes of every row per step
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f e0 = {0.f, 0.f}, e1 = {0.f, 0.f}, e2 = {0.f, 0.f}, e3 = {0.f, 0.f};
+            if (DBG != 3) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned off = ((unsigned)c << 4) ^ jj;
+                const float4 f0 = *reinterpret_cast<const float4 *>(lds + a0 + off);
+                const float4 f1 = *reinterpret_cast<const float4 *>(lds + a1 + off);
+                const float4 f2 = *reinterpret_cast<const float4 *>(lds + a2 + off);
+                const float4 f3 = *reinterpret_cast<const float4 *>(lds + a3 + off);
+                const v2f gl = {go[c].x, go[c].y}, gh = {go[c].z, go[c].w};
+                e0 = __builtin_elementwise_fma(gl, v2f{f0.x, f0.y}, e0);
+                e1 = __builtin_elementwise_fma(gl, v2f{f1.x, f1.y}, e1);
+                e2 = __builtin_elementwise_fma(gl, v2f{f2.x, f2.y}, e2);
+                e3 = __builtin_elementwise_fma(gl, v2f{f3.x, f3.y}, e3);
+                e0 = __builtin_elementwise_fma(gh, v2f{f0.z, f0.w}, e0);
+                e1 = __builtin_elementwise_fma(gh, v2f{f1.z, f1.w}, e1);
+                e2 = __builtin_elementwise_fma(gh, v2f{f2.z, f2.w}, e2);
+                e3 = __builtin_elementwise_fma(gh, v2f{f3.z, f3.w}, e3);
+                if (c & 1) __builtin_amdgcn_sched_barrier(0);      // two steps' reads in flight (the scheduler would hoist all 32: 128 registers)
+            }
+            }
+            const float s0 = e0.x + e0.y, s1 = e1.x + e1.y, s2 = e2.x + e2.y, s3 = e3.x + e3.y;
+            // reading order -> corner order: top-left, top-right, bottom-left, bottom-right
+            float d1 = sw ? s1 : s0, d2 = sw ? s0 : s1, d3 = sw ? s3 : s2, d4 = sw ? s2 : s3;
+
+            // ---- samples that left their windows: one at a time, the whole wave on its four rows
+            unsigned long long fb = __ballot(far);
+            while (fb) {
+                const int sl = (int)__builtin_ctzll(fb);
+                fb &= fb - 1;
+                const float px = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), sl));
+                const float py = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), sl));
+                const int q_s = __builtin_amdgcn_readlane(qs, sl), l_s = (sl & (LP - 1)) / P;
+                int H_ = Hs[0], W_ = Ws[0], st_ = sts[0];
+                MaskExt me = MaskExt{ves[0]};
+#pragma unroll
+                for (int l = 1; l < KL; ++l)
+                    if (l_s == l) { H_ = Hs[l]; W_ = Ws[l]; st_ = sts[l]; me = MaskExt{ves[l]}; }
+                unsigned off[4];
+                float lw_, lh_;
+                sample_setup_oob(px, py, H_, W_, st_, row_bytes, off, lw_, lh_);
+                if constexpr (MASK) mask_corners_oob(io, me, n, px, py, H_, W_, st_, off);
+                // lane -> (corner lane / 16, 8-byte piece lane % 16)
+                const int ci = lane >> 4;
+                const unsigned myoff = ci == 0 ? off[0] : (ci == 1 ? off[1] : (ci == 2 ? off[2] : off[3]));
+                const unsigned piece = (unsigned)(lane & 15) * 8u;
+                const float2 v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(vr, myoff + head_b + piece, 0, 0));
+                const float2 gg = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gr, (unsigned)(q_s * M + m) * 128u + piece, 0, 0));
+                const float dsum = lp_group_sum(v.x * gg.x + v.y * gg.y, 16);
+                const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsum), 0));
+                const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsum), 16));
+                const float c3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsum), 32));
+                const float c4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsum), 48));
+                if (lane == sl) { d1 = c1; d2 = c2; d3 = c3; d4 = c4; }
+            }
+
+            // ---- the three small gradients of my sample (.cuh:87-159 without the scatter)
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float t_ = hw * d1 + lw * d2, b_ = hw * d3 + lw * d4;
+            const float g_a = inside ? hh * t_ + lh * b_ : 0.f;
+            const float g_x = inside ? a * (hh * (d2 - d1) + lh * (d4 - d3)) : 0.f;
+            const float g_y = inside ? a * (b_ - t_) : 0.f;
+            float dot = 0.f;                       // fused epilogue: sum_k a_k g_k over the row (softmax backward)
+            if (IO::kSoftmax) dot = lp_group_sum(a * g_a, 16);
+            if (act) io.store_with_dot(row, nq, LP, k, lvl, P, myH, myW, make_float4(g_a, g_x * Wf, g_y * Hf, a), dot);
+        }
+    }
+}
