@@ -67,11 +67,17 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_SCATTER_NT 512    // (704 threads = one sample per thread, no half-empty second sample slot, two workgroups per CU:
 #endif                             //  encoder backward 726 against 678 us at bs 4 -- the third workgroup is worth more)
 #ifndef SEMIDETR_GW_NT           // msda_gw_d32 (lane-per-sample gather of the encoder backward): threads, region, margins of level 0 / the coarse levels
-#define SEMIDETR_GW_NT 768
+#define SEMIDETR_GW_NT 1024
 #define SEMIDETR_GW_RTH 16
 #define SEMIDETR_GW_RTW 16
 #define SEMIDETR_GW_H0 4
 #define SEMIDETR_GW_HC 4
+#endif
+#ifndef SEMIDETR_GW_FB
+#define SEMIDETR_GW_FB 4         // msda_gw_d32: far samples whose loads are in flight together
+#endif
+#ifndef SEMIDETR_GW_DBG
+#define SEMIDETR_GW_DBG 0        // timing aids of msda_gw_d32 (results wrong), tuning builds only
 #endif
 #ifndef SEMIDETR_RW_NT
 #define SEMIDETR_RW_NT 768       // msda_rw_d32: threads per workgroup.  Its windows take most of the LDS, so a CU holds ONE workgroup and
@@ -649,7 +655,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         if (L == 4 && P == kPT && fill_in_gather && slot_samples_are_near((flags >> 8) & 0xff)) {
             // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
             auto launch_gw = [&](auto kern) -> bool {
-                constexpr size_t wl = gw_lds_bytes<SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();
+                constexpr size_t wl = gw_lds_bytes<SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();
                 if (allow_big_lds(kern, wl, "msda_backward") != SEMIDETR_OK) {      // refused: the patch gather below
                     (void)hipGetLastError();
                     return false;
@@ -662,10 +668,10 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             };
             if constexpr (std::is_same<IO, RawIO>::value) {
                 if (io.has_mask())
-                    window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, true>);
+                    window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, true, SEMIDETR_GW_DBG>);
             }
             if (!window_gather && !io.has_mask())
-                window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false>);
+                window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false, SEMIDETR_GW_DBG>);
         }
         if (window_gather) {
         } else if (L * P == 16)             // DINO: sample loop unrolled, results in registers

@@ -26,8 +26,38 @@
 //     patch gather when the slot's forward policy says the samples are far, msda.hip).
 #pragma once
 
-template <int RTH, int RTW, int H0, int HC, int KL>
-constexpr size_t gw_lds_bytes() { return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128; }
+constexpr int kGwQList = 1024;      // queries of a region kept as a list in LDS (a region of a halving pyramid has ~340; larger ones compute them)
+constexpr int kGwFarCap = 8;        // far samples a wave hands to its rows at a time (32-byte entries in LDS)
+template <int NT, int RTH, int RTW, int H0, int HC, int KL>
+constexpr size_t gw_lds_bytes()
+{
+    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)kGwQList * 4 + (size_t)(NT / 64) * kGwFarCap * 32;
+}
+
+// four 16-lane (DPP row) sums at once, as sixteen fused v_add_f32_dpp (see group8_sum3): every lane of a row gets its row's totals
+__device__ __forceinline__ void row16_sum4(float &a, float &b, float &c, float &d)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 
 template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool MASK = false, int DBG = 0>
 __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
@@ -38,11 +68,13 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
     using Wn = RwWin<RTH, RTW, H0, HC, KL>;
     constexpr int P = kPT, LP = KL * P, QPR = NT / LP;      // queries per round
     static_assert(H0 >= 0 && LP == 16, "every level has a window; the 16 samples of a (query, head) row fill one DPP row");
-    static_assert(Wn::total * 128 <= 160 * 1024, "windows do not fit the LDS");
+    static_assert(gw_lds_bytes<NT, RTH, RTW, H0, HC, KL>() <= 160 * 1024, "windows do not fit the LDS");
     constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
 
-    extern __shared__ float4 smem[];
+    extern __shared__ __attribute__((aligned(128))) float4 smem[];      // (the chunk swizzle XORs into row addresses)
     char *const lds = reinterpret_cast<char *>(smem);
+    int *const qlist = reinterpret_cast<int *>(lds + Wn::total * 128);                                  // the region's queries, in slot order
+    char *const farl = lds + Wn::total * 128 + kGwQList * 4 + (threadIdx.x >> 6) * (kGwFarCap * 32);    // my wave's far-sample entries
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int k = tid & (LP - 1), lvl = k / P;            // my sample of the row, its level
@@ -147,7 +179,11 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             unsigned smk[MASK ? kMaxSteps : 1];
             const unsigned char *mask_n = nullptr;
             if constexpr (MASK) mask_n = io.mask + (int64_t)n * S;
-            const int ocs = tid >> 3, j8s = tid & 7;
+            // (the thread index through an empty asm: the per-step window coordinates below depend on nothing else, and hoisted out of
+            //  the region loop they are ~40 registers held for the whole kernel -- msda_rw_d32's "lean" staging)
+            int tids = tid;
+            asm volatile("" : "+v"(tids));
+            const int ocs = tids >> 3, j8s = tids & 7;
             const unsigned lane_bs = head_b + (unsigned)j8s * 16u;
             int nst = 0;
 #pragma unroll
@@ -163,7 +199,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                         smk[nst] = 0u;
                         if (ves[l] < 0) smk[nst] = mask_n[ok ? sts[l] + py * Ws[l] + px : 0];
                     }
-                    sv[nst++] = buf_ld4(vr, goff);
+                    sv[nst++] = DBG == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : buf_ld4(vr, goff);
                     r += RPS;
                     wx += RPS % ww_;
                     wy += RPS / ww_;
@@ -193,24 +229,61 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                 }
             }
             if (ocs < Wn::zrows) *reinterpret_cast<float4 *>(lds + kZ0 + ocs * 128 + j8s * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            // the region's query list (slot -> pixel): worked out once here instead of by every lane in every round (~40 instructions)
+            // (whole waves at a time: slot_query shuffles from lanes 0 .. KL-1, which must be active)
+            if (nq_total <= kGwQList)
+                for (int s0_ = tids & ~63; s0_ < nq_total; s0_ += NT) {
+                    const int s_ = s0_ + (tids & 63), q_ = slot_query(s_);
+                    if (s_ < nq_total) qlist[s_] = q_;
+                }
         }
         __syncthreads();                   // the windows are complete
+        const bool listed = nq_total <= kGwQList;
+        auto query_of_slot = [&](int s_) -> int { return listed ? (s_ < nq_total ? qlist[s_] : -1) : slot_query(s_); };
 
         const int nrounds = (nq_total + QPR - 1) / QPR;
-        for (int round = 0; round < nrounds; ++round) {
-            const int q = slot_query(round * QPR + (tid >> 4));
-            if (!__any(q >= 0)) break;     // queries are dealt out in order: a wave without one has none later either
-            const bool act = q >= 0;
-            const int qs = act ? q : 0;    // (a lane without a query reads query 0 of the image and stores nothing)
-            const int64_t nq = (int64_t)n * Lq + qs, row = nq * M + m;
-            // ---- my sample's data and my query's grad_out row (chunks in my swizzle order)
-            float x, y;
-            io.load_xy(row, nq, LP, k, lvl, P, myH, myW, x, y);
-            const float raw = io.load_w(row, LP, k);
-            float4 go[8];
-            const unsigned gbase = (unsigned)(qs * M + m) * 128u;
+        // A round's data is loaded ahead of its use (without that every wave waited a full memory round trip per round, with three
+        // waves per SIMD to hide it): my sample's location / weight a round ahead; my query's grad_out row (32 registers, chunks in my
+        // swizzle order) as soon as the previous round's dot loop is done with those registers -- behind it lie that round's far
+        // samples, results and stores and this round's softmax and geometry.
+        struct Pre {
+            int q;
+            typename IO::RawXY rxy;
+            float raw;
+        };
+        auto fetch = [&](int round_, Pre &p) {
+            p.q = query_of_slot(round_ * QPR + (tid >> 4));
+            const int qs_ = p.q >= 0 ? p.q : 0;       // (a lane without a query reads query 0 of the image and stores nothing)
+            const int64_t nq_ = (int64_t)n * Lq + qs_, row_ = nq_ * M + m;
+            p.rxy = io.load_xy_raw(row_, nq_, LP, k, lvl);
+            p.raw = io.load_w(row_, LP, k);
+        };
+        float4 go[8];
+        // (my chunk swizzle goes through an empty asm where it is used: the compiler would otherwise keep all its derived offsets --
+        //  8 for the grad_out loads, 8 for the window reads -- in registers for the whole kernel and spill a hundred others)
+        auto fetch_go = [&](int q_, unsigned jr) {
+            const unsigned gbase = (unsigned)((q_ >= 0 ? q_ : 0) * M + m) * 128u + jr;      // (aligned to 128: + is ^)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) go[c] = buf_ld4(gr, gbase + (((unsigned)c << 4) ^ jj));
+            for (int c = 0; c < 8; ++c) go[c] = buf_ld4(gr, gbase ^ ((unsigned)c << 4));
+        };
+        Pre nxt;
+        fetch(0, nxt);
+        {
+            unsigned jr = jj;
+            asm volatile("" : "+v"(jr));
+            fetch_go(nxt.q, jr);
+        }
+        for (int round = 0; round < nrounds; ++round) {
+            const Pre cur = nxt;
+            const int q = cur.q;
+            if (!__any(q >= 0)) break;     // queries are dealt out in order: a wave without one has none later either
+            if (round + 1 < nrounds) fetch(round + 1, nxt);
+            const bool act = q >= 0;
+            const int qs = act ? q : 0;
+            const int64_t nq = (int64_t)n * Lq + qs, row = nq * M + m;
+            float x, y;
+            io.finish_xy_raw(cur.rxy, P, myH, myW, x, y);
+            const float raw = cur.raw;
             const float a = row_softmax(io, row, LP, k, raw);      // fused prologue: over the 16 lanes of my DPP row
 
             // ---- geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 zero padding)
@@ -234,14 +307,20 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             // ---- four dots <grad_out, corner row>, 16 bytes of every row per step
             typedef float v2f __attribute__((ext_vector_type(2)));
             v2f e0 = {0.f, 0.f}, e1 = {0.f, 0.f}, e2 = {0.f, 0.f}, e3 = {0.f, 0.f};
+            unsigned jl = jj;
+            asm volatile("" : "+v"(jl));
+            // (rows are 128-byte aligned, and so is the window array: my first chunk of each row, as LDS addresses)
+            const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)lds;
+            const unsigned b0 = (lds0 + a0) ^ jl, b1 = (lds0 + a1) ^ jl, b2 = (lds0 + a2) ^ jl, b3 = (lds0 + a3) ^ jl;
             if (DBG != 3) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const unsigned off = ((unsigned)c << 4) ^ jj;
-                const float4 f0 = *reinterpret_cast<const float4 *>(lds + a0 + off);
-                const float4 f1 = *reinterpret_cast<const float4 *>(lds + a1 + off);
-                const float4 f2 = *reinterpret_cast<const float4 *>(lds + a2 + off);
-                const float4 f3 = *reinterpret_cast<const float4 *>(lds + a3 + off);
+                // (32-bit LDS addresses formed by hand: through the generic `lds + offset` every read carried an add of the array's base)
+                typedef const __attribute__((address_space(3))) char *lds_cptr;
+                const float4 f0 = *reinterpret_cast<const float4 *>((const char *)(lds_cptr)(uintptr_t)(b0 ^ ((unsigned)c << 4)));
+                const float4 f1 = *reinterpret_cast<const float4 *>((const char *)(lds_cptr)(uintptr_t)(b1 ^ ((unsigned)c << 4)));
+                const float4 f2 = *reinterpret_cast<const float4 *>((const char *)(lds_cptr)(uintptr_t)(b2 ^ ((unsigned)c << 4)));
+                const float4 f3 = *reinterpret_cast<const float4 *>((const char *)(lds_cptr)(uintptr_t)(b3 ^ ((unsigned)c << 4)));
                 const v2f gl = {go[c].x, go[c].y}, gh = {go[c].z, go[c].w};
                 e0 = __builtin_elementwise_fma(gl, v2f{f0.x, f0.y}, e0);
                 e1 = __builtin_elementwise_fma(gl, v2f{f1.x, f1.y}, e1);
@@ -254,39 +333,65 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                 if (c & 1) __builtin_amdgcn_sched_barrier(0);      // two steps' reads in flight (the scheduler would hoist all 32: 128 registers)
             }
             }
+            // The next round's grad_out rows go into the registers the loop has just released.  ONE empty asm takes the eight partial
+            // sums and hands out the swizzle the loads' addresses are built from: the compiler can neither sink the FMAs below the loads
+            // (it did: two sets of rows live, the window reads spilled to scratch) nor hoist the loads above them.
+            {
+                unsigned jr = jj;
+                asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(jr));
+                if (round + 1 < nrounds) fetch_go(nxt.q, jr);
+            }
             const float s0 = e0.x + e0.y, s1 = e1.x + e1.y, s2 = e2.x + e2.y, s3 = e3.x + e3.y;
             // reading order -> corner order: top-left, top-right, bottom-left, bottom-right
             float d1 = sw ? s1 : s0, d2 = sw ? s0 : s1, d3 = sw ? s3 : s2, d4 = sw ? s2 : s3;
 
-            // ---- samples that left their windows: one at a time, the whole wave on its four rows
-            unsigned long long fb = __ballot(far);
-            while (fb) {
-                const int sl = (int)__builtin_ctzll(fb);
-                fb &= fb - 1;
-                const float px = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), sl));
-                const float py = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), sl));
-                const int q_s = __builtin_amdgcn_readlane(qs, sl), l_s = (sl & (LP - 1)) / P;
-                int H_ = Hs[0], W_ = Ws[0], st_ = sts[0];
-                MaskExt me = MaskExt{ves[0]};
-#pragma unroll
-                for (int l = 1; l < KL; ++l)
-                    if (l_s == l) { H_ = Hs[l]; W_ = Ws[l]; st_ = sts[l]; me = MaskExt{ves[l]}; }
-                unsigned off[4];
+            // ---- samples that left their windows: the whole wave on their rows, four samples per trip (their loads in flight together:
+            //      one at a time, every sample cost a memory round trip -- 4.4 us per round, the whole kernel's time).  The owner
+            //      lane works out the four corner offsets (kOob: outside the level / padded); lane -> (corner lane / 16, 8-byte piece lane % 16)
+            unsigned foff[4] = {kOob, kOob, kOob, kOob};
+            if (far) {
                 float lw_, lh_;
-                sample_setup_oob(px, py, H_, W_, st_, row_bytes, off, lw_, lh_);
-                if constexpr (MASK) mask_corners_oob(io, me, n, px, py, H_, W_, st_, off);
-                // lane -> (corner lane / 16, 8-byte piece lane % 16)
-                const int ci = lane >> 4;
-                const unsigned myoff = ci == 0 ? off[0] : (ci == 1 ? off[1] : (ci == 2 ? off[2] : off[3]));
+                sample_setup_oob(x, y, myH, myW, myst, row_bytes, foff, lw_, lh_);
+                if constexpr (MASK) mask_corners_oob(io, MaskExt{lvl == 0 ? ves[0] : (lvl == 1 ? ves[1] : (lvl == 2 ? ves[2] : ves[KL - 1]))}, n, x, y, myH, myW, myst, foff);
+            }
+            const unsigned long long fb = DBG == 4 ? 0ull : __ballot(far);
+            if (fb) {      // (wave-uniform)
+                // Every far sample becomes a 32-byte entry {4 corner offsets, query} in my wave's LDS list, at its rank among the wave's
+                // far samples; then each of the wave's four 16-lane rows takes one entry per trip: lane -> 8-byte piece of the rows,
+                // four products with the query's grad_out piece, four DPP row sums, the dots go back through the entry.  (One sample
+                // per WAVE and trip, with readlane broadcasts, was ~35 instructions per sample: as much as the whole window path.)
+                const int nfar = __builtin_popcountll(fb);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fb, 0u));
+                const int rrow = lane >> 4;
                 const unsigned piece = (unsigned)(lane & 15) * 8u;
-                const float2 v = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(vr, myoff + head_b + piece, 0, 0));
-                const float2 gg = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gr, (unsigned)(q_s * M + m) * 128u + piece, 0, 0));
-                const float dsum = lp_group_sum(v.x * gg.x + v.y * gg.y, 16);
-                const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsum), 0));
-                const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsum), 16));
-                const float c3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsum), 32));
-                const float c4 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dsum), 48));
-                if (lane == sl) { d1 = c1; d2 = c2; d3 = c3; d4 = c4; }
+                for (int base = 0; base < nfar; base += kGwFarCap) {
+                    const bool mine = far && rank >= base && rank < base + kGwFarCap;
+                    if (mine) {
+                        *reinterpret_cast<uint4 *>(farl + (rank - base) * 32) = make_uint4(foff[0], foff[1], foff[2], foff[3]);
+                        *reinterpret_cast<int *>(farl + (rank - base) * 32 + 16) = qs;
+                    }
+                    const int nhere = min(nfar - base, kGwFarCap);
+                    for (int e0_ = 0; e0_ < nhere; e0_ += 4) {
+                        const int e_ = e0_ + rrow;
+                        const bool on = e_ < nhere;
+                        const uint4 o = *reinterpret_cast<const uint4 *>(farl + (on ? e_ : 0) * 32);
+                        const int q_s = *reinterpret_cast<const int *>(farl + (on ? e_ : 0) * 32 + 16);
+                        const unsigned hb = head_b + piece;
+                        const float2 v0 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(vr, on ? o.x + hb : kOob, 0, 0));
+                        const float2 v1 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(vr, on ? o.y + hb : kOob, 0, 0));
+                        const float2 v2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(vr, on ? o.z + hb : kOob, 0, 0));
+                        const float2 v3 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(vr, on ? o.w + hb : kOob, 0, 0));
+                        const float2 gg = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(gr, (unsigned)(q_s * M + m) * 128u + piece, 0, 0));
+                        float p0 = v0.x * gg.x + v0.y * gg.y, p1 = v1.x * gg.x + v1.y * gg.y;
+                        float p2 = v2.x * gg.x + v2.y * gg.y, p3 = v3.x * gg.x + v3.y * gg.y;
+                        row16_sum4(p0, p1, p2, p3);
+                        if (on && (lane & 15) == 0) *reinterpret_cast<float4 *>(farl + e_ * 32) = make_float4(p0, p1, p2, p3);
+                    }
+                    if (mine) {
+                        const float4 dd = *reinterpret_cast<const float4 *>(farl + (rank - base) * 32);
+                        d1 = dd.x; d2 = dd.y; d3 = dd.z; d4 = dd.w;
+                    }
+                }
             }
 
             // ---- the three small gradients of my sample (.cuh:87-159 without the scatter)
