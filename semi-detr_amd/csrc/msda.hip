@@ -67,7 +67,7 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_SCATTER_NT 512    // (704 threads = one sample per thread, no half-empty second sample slot, two workgroups per CU:
 #endif                             //  encoder backward 726 against 678 us at bs 4 -- the third workgroup is worth more)
 #ifndef SEMIDETR_GW_NT           // msda_gw_d32 (lane-per-sample gather of the encoder backward): threads, region, margins of level 0 / the coarse levels
-#define SEMIDETR_GW_NT 1024
+#define SEMIDETR_GW_NT 768
 #define SEMIDETR_GW_RTH 16
 #define SEMIDETR_GW_RTW 16
 #define SEMIDETR_GW_H0 4
@@ -522,8 +522,12 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, F
     return SEMIDETR_OK;
 }
 
-// what the slot's forward choice says about its samples, for the BACKWARD's gather (same data, one forward earlier): true = they stay
-// near their queries (the window kernels pay).  Reads the state, counts nothing.
+// What the slot's forward launches counted about its samples, for the BACKWARD's gather (same data, one forward earlier): true = few enough
+// of them are far from their queries for the lane-per-sample window gather (msda_gw.h) to pay.  It crosses the patch gather earlier
+// than the window forward crosses the patch forward (tools/r05_gw_sigma.sh, bs 4, whole backward: 572 / 635 / 796 / 976 / 1157 us
+// against 659 / 707 / 834 / 986 / 1111 us at sigma 1 / 2 / 3 / 4 / 5 px; bs 1 level at 3 px): below a far share of ~0.45
+// (sigma ~3.5 px).  Reads the state, counts nothing; no count received yet = the patch gather.
+constexpr float kFarToWindowGather = 0.45f;
 bool slot_samples_are_near(int slot_id)
 {
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
@@ -531,7 +535,9 @@ bool slot_samples_are_near(int slot_id)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
     std::lock_guard<std::mutex> lock(g_adapt_mu);
-    return g_adapt[dev] && g_adapt[dev]->slot[slot_id & (kPolicySlots - 1)].mode == 1;
+    if (!g_adapt[dev]) return false;
+    const FwdSlot &sl = g_adapt[dev]->slot[slot_id & (kPolicySlots - 1)];
+    return sl.updates > 0 && sl.last_frac >= 0.f && sl.last_frac < kFarToWindowGather;
 }
 
 // ---- product dispatch of the fast path (fp32, channels == 32), shared by the reference contract (LocAttnIO) and the
