@@ -51,8 +51,8 @@ RECIPES = {
 ROT = 6                                                     # distinct input sets per MSDA group: one per layer of a pass
 GRAD_ELEMS = 60_000_000                                     # student DINO-R50 + projector
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_JSON = "r04_pmc_traffic.json"                           # written by tools/measure_traffic.py (rocprofv3 --pmc passes)
-TA_JSON = "r04_fwd_enc_TA.json"                             # written by tools/r04_fwd_ta_evidence.sh
+PMC_JSON = "r05_pmc_traffic.json"                           # written by tools/measure_traffic.py (rocprofv3 --pmc passes)
+TA_JSON = "r05_fwd_enc_TA.json"                             # written by tools/r05_fwd_ta_evidence.sh
 
 
 def msda_alg_bytes(N, Lq, backward, S=S, L=L):
@@ -1077,7 +1077,7 @@ def main():
         fdur = fg["ms"] * 1e-3 / fg["launches"]
         clock_mhz = torch.cuda.get_device_properties(dev).clock_rate / 1e3 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2400.0
         l1_peak = 256 * 64 * 2400e6 / 1e9
-        # observed clock / TA busy fraction of this kernel: measured by tools/r04_fwd_ta_evidence.sh (rocprofv3 --pmc), read
+        # observed clock / TA busy fraction of this kernel: measured by tools/r05_fwd_ta_evidence.sh (rocprofv3 --pmc), read
         # from the committed summary rather than carried as constants
         try:      # (one entry per forward kernel: the one this run's encoder forward launched)
             ran = (wl.kernels.get("msda_fwd_enc_bs%d_Lq%d" % (wl.n_unsup, wl.S)) or ["msda_fwd_d32"])[0].split("<")[0]
@@ -1085,6 +1085,33 @@ def main():
             obs_mhz, ta_frac = float(ta_ev["observed_clock_mhz"]), float(ta_ev["ta_busy_frac"])
         except (OSError, ValueError, KeyError, TypeError):
             ta_ev, obs_mhz, ta_frac = None, None, None
+        # Second view of the encoder forward: the on-chip data paths of the kernel that RAN.  The patch kernel pulls every
+        # corner row (4 x 128 B per sample) through the vector-memory data return (64 B/clk/CU).  The region-window kernel serves the
+        # coarse levels' corner rows from LDS windows (ds_read_b128: 256 B/clk/CU, MI355X_MICROARCH.md) and only level 0's through the
+        # vector-memory path (plus the few samples that leave their windows, not counted here): two pipes, both far from full --
+        # the kernel is a latency chain at three waves per SIMD, not bound by either (ta_busy_frac_pmc says the same).
+        window_fwd = any("msda_rw_d32" in x for x in wl.kernels.get(fwd_name, []))
+        l1_bytes = corner_bytes / wl.L if window_fwd else corner_bytes
+        lds_bytes = corner_bytes * (wl.L - 1) / wl.L if window_fwd else 0
+        lds_peak = 256 * 256 * 2400e6 / 1e9
+        roofline_l1 = {"bound": "l1_return", "kernel": fwd_name, "kernel_symbols": wl.kernels.get(fwd_name, []),
+                       "achieved": l1_bytes / fdur / 1e9, "peak": l1_peak, "unit": "GB/s", "frac": l1_bytes / fdur / 1e9 / l1_peak,
+                       "frac_at_observed_clock": (l1_bytes / fdur / 1e9 / (256 * 64 * obs_mhz * 1e6 / 1e9)) if obs_mhz else None,
+                       "lds_return": ({"achieved": lds_bytes / fdur / 1e9, "peak": lds_peak, "unit": "GB/s",
+                                       "frac": lds_bytes / fdur / 1e9 / lds_peak, "bytes_per_launch": lds_bytes} if window_fwd else None),
+                       "observed_clock_mhz": obs_mhz, "ta_busy_frac_pmc": ta_frac,
+                       "pmc_source": ("profiles/" + TA_JSON) if ta_ev else None,
+                       "note": ("region-window kernel: level-0 corner rows (1 / L of the 4 x 128 B per sample; far samples of the coarse "
+                                "levels not counted) through the vector-memory return vs 256 CU x 64 B/clk x 2400 MHz, the coarse levels' "
+                                "corner rows from LDS (`lds_return`) vs 256 CU x 256 B/clk x 2400 MHz -- neither pipe is the limit, "
+                                "the kernel is a chain of dependent phases per round at three waves per SIMD (DESIGN.md 2.1b)"
+                                if window_fwd else
+                                "patch kernel: corner rows (4 x 128 B per sample) / launch time vs 256 CU x 64 B/clk x 2400 MHz; this "
+                                "vector-memory INSTRUCTION path (16 cycles per 64-lane buffer_load_dwordx4) is what binds it "
+                                "(DESIGN.md 2.1)") +
+                               "; observed clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time and TA busy = TA_BUSY_avr / active cycles, "
+                               "read from profiles/" + TA_JSON + " for the kernel that ran (rocprofv3 --pmc, probe inputs; null when absent)",
+                       "l1_bytes_per_launch": l1_bytes, "device_clock_mhz_reported": clock_mhz}
         out = {
             "metric": "images/sec/node DINO-R50 SSOD step (hot path: MSDA fwd/bwd + Hungarian + EMA/pseudo-label)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1102,21 +1129,7 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": roofline_of(dom_name),
             "roofline_largest_group": roofline_of(big_name) if big_name != dom_name else None,
-            "roofline_l1": {"bound": "l1_return", "kernel": fwd_name, "kernel_symbols": wl.kernels.get(fwd_name, []),
-                            "achieved": corner_bytes / fdur / 1e9, "peak": l1_peak, "unit": "GB/s",
-                            "frac": corner_bytes / fdur / 1e9 / l1_peak,
-                            "frac_at_observed_clock": (corner_bytes / fdur / 1e9 / (256 * 64 * obs_mhz * 1e6 / 1e9)) if obs_mhz else None,
-                            "observed_clock_mhz": obs_mhz, "ta_busy_frac_pmc": ta_frac,
-                            "pmc_source": ("profiles/" + TA_JSON) if ta_ev else None,
-                            "note": "corner rows (4 x 128 B per sample) / launch time vs 256 CU x 64 B/clk x 2400 MHz; "
-                                    "observed clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time and TA busy = TA_BUSY_avr / "
-                                    "active cycles, both read from profiles/" + TA_JSON + " (rocprofv3 --pmc, same kernel, probe "
-                                    "inputs; null when that file is missing).  This vector-memory INSTRUCTION path (16 cycles per 64-lane "
-                                    "buffer_load_dwordx4: 450 k cycles per CU and launch = 84 % of the kernel at that clock) "
-                                    "is what binds the forward and the gather; taking accesses off it through LDS cost more "
-                                    "than it returned three times (DESIGN.md 2.1, profiles/r02_fwd_resident_level_pmc.txt, "
-                                    "profiles/r02_lds_window_forward.txt)",
-                            "corner_bytes_per_launch": corner_bytes, "device_clock_mhz_reported": clock_mhz},
+            "roofline_l1": roofline_l1,
             "rooflines_all_msda_groups": {k: {"frac_hbm_peak": roofline_of(k)["frac"], "avg_launch_us": roofline_of(k)["avg_launch_us"],
                                               "kernels": wl.kernels.get(k, [])} for k in sorted(msda)},
             "forward_policy": wl.sda._lib.forward_policy_state(),      # encoder forward kernel choice after the timed steps

@@ -553,11 +553,51 @@ def gen_ema():
     np.savez_compressed(os.path.join(OUT, "ema.npz"), **d)
 
 
+def load_dino_detr_ssod():
+    """detr_ssod/models/dino_detr_ssod.py imported as it is, with stand-in modules for what its import lines name (mmcv / mmdet /
+    detr_ssod are not installed; none of those names is touched by the method called below)."""
+    def mod(name, **attrs):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Registry:
+        def register_module(self, *a, **k):
+            return lambda cls: cls
+
+    def _unused(*a, **k):
+        raise AssertionError("stand-in called: the fixture generator must not need it")
+
+    mod("mmcv")
+    mod("mmcv.runner", get_dist_info=lambda: (0, 1))
+    mod("mmcv.runner.fp16_utils", force_fp32=lambda *a, **k: (lambda f: f))
+    mod("mmdet")
+    mod("mmdet.core", **{n: _unused for n in ("bbox2roi", "bbox_cxcywh_to_xyxy", "bbox_xyxy_to_cxcywh", "build_assigner",
+                                               "build_sampler", "multi_apply", "reduce_mean")})
+    mod("mmdet.models", DETECTORS=_Registry(), build_detector=_unused)
+    mod("mmdet.models.utils")
+    mod("mmdet.models.utils.transformer", inverse_sigmoid=_unused)
+    mod("mmdet.models.builder", build_roi_extractor=_unused)
+    mod("detr_ssod")
+    mod("detr_ssod.models")
+    mod("detr_ssod.models.multi_stream_detector", MultiSteamDetector=type("MultiSteamDetector", (torch.nn.Module,), {}))
+    mod("detr_ssod.models.utils", Transform2D=_unused, filter_invalid_class_wise=_unused, concat_all_gather=_unused)
+    mod("detr_ssod.utils", log_every_n=_unused, log_image_with_boxes=_unused)
+    mod("detr_ssod.utils.structure_utils", dict_split=_unused, weighted_loss=_unused)
+    return _load("ref_dino_detr_ssod", os.path.join(REF, "detr_ssod", "models", "dino_detr_ssod.py"))
+
+
 def gen_pseudo():
-    """dino_detr_ssod.py:918-939 restated with the same torch calls."""
+    """DinoDetrSSOD.extract_teacher_info (detr_ssod/models/dino_detr_ssod.py:893-951) ITSELF, called unbound on a stand-in `self`
+    whose teacher returns the seeded proposal tables: det_bboxes / det_labels / det_scores are the reference's outputs.  `keep` =
+    where those rows sit in the proposal table (rows are distinct), `thr` = the sum of the two values the reference's own
+    torch.mean / torch.std calls returned (recorded through a pass-through proxy of the module's `torch`)."""
+    ref = load_dino_detr_ssod()
     d = {}
     g = torch.Generator().manual_seed(13)
-    names = []
+    names, props, labs = [], [], []
     for k, K in enumerate((300, 57, 2, 1, 0, 128)):
         xy = torch.rand(K, 2, generator=g) * 800
         wh = torch.rand(K, 2, generator=g) * 300 - (20 if k in (1, 5) else 0)   # some w/h <= 0
@@ -565,20 +605,46 @@ def gen_pseudo():
         box = torch.cat([xy, xy + wh, score], -1)
         if K == 0:
             box = box.new_zeros(0, 5)
-        lab = torch.randint(0, 80, (K,), generator=g)
-        if K > 0:
-            thr = torch.mean(box[:, -1]) + torch.std(box[:, -1])
-            valid = torch.nonzero(box[:, -1] >= thr, as_tuple=False).squeeze().unique()
-            tmp = box[valid, :4]
-            ok = ((tmp[:, 2] - tmp[:, 0]) > 0) & ((tmp[:, 3] - tmp[:, 1]) > 0)
-            valid = valid[ok]
-            thr = thr.numpy()
-        else:
-            valid, thr = torch.zeros(0, dtype=torch.long), np.float32("nan")
-        n = f"p{k}_K{K}"
-        names.append(n)
-        d[f"{n}.proposal"], d[f"{n}.labels"] = box.numpy(), lab.numpy()
-        d[f"{n}.keep"], d[f"{n}.thr"] = valid.numpy().astype(np.int64), np.float32(thr)
+        props.append(box)
+        labs.append(torch.randint(0, 80, (K,), generator=g))
+        names.append(f"p{k}_K{K}")
+
+    class _TorchProxy:
+        """the module's `torch`, passing everything through and remembering what mean / std returned"""
+        def __init__(self):
+            self.means, self.stds = [], []
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        def mean(self, *a, **k):
+            r = torch.mean(*a, **k)
+            self.means.append(r)
+            return r
+
+        def std(self, *a, **k):
+            r = torch.std(*a, **k)
+            self.stds.append(r)
+            return r
+
+    proxy = _TorchProxy()
+    ref.torch = proxy
+    head = types.SimpleNamespace(simple_test_bboxes=lambda feat, metas, **kw: list(zip(props, labs)))
+    fake = types.SimpleNamespace(teacher=types.SimpleNamespace(extract_feat=lambda img: [torch.zeros(1, 1)], bbox_head=head), curr_step=0)
+    metas = [dict(transform_matrix=np.eye(3, dtype=np.float32)) for _ in props]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # std() of one / no element
+        info = ref.DinoDetrSSOD.extract_teacher_info(fake, torch.zeros(1), metas)
+    ref.torch = torch
+    for i, n in enumerate(names):
+        box, kept = props[i], info["det_bboxes"][i]
+        assert len(torch.unique(box, dim=0)) == len(box)
+        keep = [int(torch.nonzero((box[:, :4] == r).all(-1) & (box[:, 4] == s)).item()) for r, s in zip(kept, info["det_scores"][i])]
+        assert torch.equal(info["det_labels"][i], labs[i][keep])
+        d[f"{n}.proposal"], d[f"{n}.labels"] = box.numpy(), labs[i].numpy()
+        d[f"{n}.keep"] = np.asarray(keep, np.int64)
+        d[f"{n}.thr"] = np.float32((proxy.means[i] + proxy.stds[i]).numpy()) if len(box) else np.float32("nan")
     d["names"] = np.asarray(names)
     np.savez_compressed(os.path.join(OUT, "pseudo.npz"), **d)
 

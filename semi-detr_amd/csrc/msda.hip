@@ -42,7 +42,7 @@
 namespace {
 
 constexpr int kMaxLevels = 32;
-// A/B knobs of tools/r04_ab_multi.sh (same-box comparison of several builds inside the bench step).  Round 4, rotated inputs:
+// A/B knobs of tools/archive/r04_ab_multi.sh (same-box comparison of several builds inside the bench step).  Round 4, rotated inputs:
 // encoder gather with 8 instead of 16 corner loads in flight at five waves per SIMD: backward 701 -> 695 us at bs 4 (with
 // replayed inputs round 2 had measured it level); region scatter with 176 queries per pass at six waves per SIMD (three
 // workgroups per CU): with 13 VGPRs spilled 702 vs 701 us at bs 4, 205 vs 196 us at bs 1; once the thread-derived constants were
@@ -437,7 +437,7 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 //      handed to the host by the first thread of launch k + 1 through mapped pinned memory, and the dispatcher -- whenever it
 //      next gets here, it never waits -- moves between the kernels with hysteresis.  Per device; a mutex serialises the few
 //      host words.  semidetr_msda_set_forward_policy pins the choice (tests, A/B timing).
-// Thresholds re-measured with the 768 / 1024-thread window kernels (tools/r04_rw_cross2.sh, rotated inputs, bs 4): four levels 233 /
+// Thresholds re-measured with the 768 / 1024-thread window kernels (tools/archive/r04_rw_cross2.sh, rotated inputs, bs 4): four levels 233 /
 // 243 / 251 / 261 / 283 us against the patch kernel's 270-273 us at sigma 3.5 / 4 / 4.5 / 5 / 6 px -- level at ~5.5 px = a far share of
 // ~0.71; five levels level at ~5 px = ~0.67.  One image alone (616 regions x heads for 256 CUs) used to need its own, lower bound;
 // the larger workgroups removed the difference (57 / 63 / 65.5 / 68.5 against 68 / 70.5 / 71.5 / 72 us at 2 / 3 / 3.5 / 4 px).

@@ -74,7 +74,7 @@ int launch_rw_cfg(int cfg, hipStream_t st, const float *grad_out, const float *v
         case 55: if constexpr (!GATHER) return RWT(768, 22, 16, -1, 5, 0, 1920); else break;     // region heights by how evenly their queries fill rounds of 96: 22 rows = 4.87
         case 56: if constexpr (!GATHER) return RWT(768, 25, 16, -1, 5, 0, 1920); else break;     // 25 rows = 5.53 (and four region rows exactly on a 100-row level)
         case 57: if constexpr (!GATHER) return RWT(768, 20, 16, -1, 5, 0, 1920); else break;     // 20 rows = 4.43
-        case 50: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 1, 1920); else break;     // the product configuration, instrumented (tools/r03_rw_dbg.py 750)
+        case 50: if constexpr (!GATHER) return RWT(768, 24, 16, -1, 5, 1, 1920); else break;     // the product configuration, instrumented (tools/archive/r03_rw_dbg.py 750)
         case 32: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 220); else break;      // the product shape, lean
         case 33: if constexpr (!GATHER) return RWT(512, 16, 16, -1, 6, 0, 240); else break;      // ... four samples between barriers again
         case 34: if constexpr (!GATHER) return RWT(768, 16, 16, -1, 6, 0, 320); else break;      // the PRODUCT configuration: 12 waves per CU, margin 6
@@ -464,7 +464,7 @@ int exp_launch_fast_backward(hipStream_t st, const float *grad_out, const float 
         SEMIDETR_REQUIRE(pixels && S < (1 << 24), SEMIDETR_E_BADARG,
                          "msda_backward: the self-attention kernels need SEMIDETR_MSDA_QUERIES_ARE_PIXELS and spatial_size < 2^24");
         // the unrolled gather launch clears grad_value as a side job (no hipMemsetAsync): the scatter that accumulates into it
-        // is the NEXT launch.  Measured (tools/r02_fillgather_try.sh): encoder bs 4 774 -> 766 us, bs 1 204 -> 201 us; 6991
+        // is the NEXT launch.  Measured (tools/archive/r02_fillgather_try.sh): encoder bs 4 774 -> 766 us, bs 1 204 -> 201 us; 6991
         // forces the memset.  (The same idea for arbitrary query sets -- gather + fill, then the level scatter as a second
         // launch, variant 901 -- loses against the merged launch: micro-benchmark 36.2 -> 41-44 us, decoder bs 4 161 -> 169.)
         const bool rw_gather = g_bwd_variant >= 7000 && g_bwd_variant <= 7009 && P == kPT && (L == 4 || L == 5);

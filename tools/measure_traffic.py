@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Measure the HBM-side traffic of the MSDA launches bench.py times and write profiles/r04_pmc_traffic.json.
+"""Measure the HBM-side traffic of the MSDA launches bench.py times and write profiles/<round>_pmc_traffic.json (SEMIDETR_ROUND, default r05).
 
 Run on the GPU box:   python tools/measure_traffic.py
 For each event group of the bench step (encoder / decoder, forward / backward, the batch sizes of the step) it runs
@@ -26,9 +26,13 @@ GROUPS = [  # bench group name, probe arguments
     ("msda_fwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "patch"]),
     # the same launch through the region-window kernel (what the adaptive policy runs at this sample spread)
     ("msda_fwd_enc_bs4_Lq22223_window", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "window"]),
-    ("msda_bwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "bwd"]),
+    ("msda_bwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "bwd", "--policy", "patch"]),
+    # ... with the lane-per-sample window gather (round 5; what the adaptive policy runs at this sample spread)
+    ("msda_bwd_enc_bs4_Lq22223_window", ["--shape", "enc", "--bs", "4", "--dir", "bwd", "--policy", "window"]),
     ("msda_fwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "fwd", "--policy", "patch"]),
-    ("msda_bwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "bwd"]),
+    ("msda_bwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "bwd", "--policy", "patch"]),
+    ("msda_fwd_enc_bs1_Lq22223_window", ["--shape", "enc", "--bs", "1", "--dir", "fwd", "--policy", "window"]),
+    ("msda_bwd_enc_bs1_Lq22223_window", ["--shape", "enc", "--bs", "1", "--dir", "bwd", "--policy", "window"]),
     ("msda_fwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "fwd"]),
     ("msda_bwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "bwd"]),
     ("msda_bwd_dec_bs1_Lq1100", ["--shape", "dec", "--bs", "1", "--lq", "1100", "--dir", "bwd"]),
@@ -94,7 +98,7 @@ def main():
             raise SystemExit("%s: msda kernels in the trace the library did not report: %r" % (group, stray))
         res[group] = {"kernels": rep_f, "per_kernel": kernels, "hbm_bytes_corrected": int(total)}
         print(group, rep_f, "%.1f MB" % (total / 1e6), flush=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r04_pmc_traffic.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", os.environ.get("SEMIDETR_ROUND", "r05") + "_pmc_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
 
 
