@@ -152,8 +152,8 @@ int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, 
  * produce the same results at different speeds depending on how far the learned offsets reach:
  *   patch kernel   -- 4 x 8 query patches, every corner row through the vector-memory path; insensitive to the offsets
  *   window kernel  -- regions of up to 25 x 16 pixels, the coarse levels' corner rows from LDS windows +- 5 px (five levels: +- 4 px) around
- *                     the region; 10-25 % faster while most samples stay inside, level with the patch kernel when ~70 % of
- *                     them are more than 4 px away (sigma ~5.5 px), slower beyond
+ *                     the region; ~30 % faster while most samples stay inside (sigma <= 2 px), level with the patch kernel when
+ *                     ~70 % of them are more than 4 px away (sigma ~5.5 px), slower beyond (profiles/r04_region_window_dispatch.txt)
  * policy 0 (default, adaptive): both kernels count, in a few workgroups, the share of samples further than 4 px from their
  *   query's pixel centre; launch k's count reaches the host through mapped pinned memory when launch k + 1 OF THE SAME SLOT starts
  *   (no copy command, no synchronisation) and the NEXT dispatch of that slot moves between the kernels with hysteresis (to the
@@ -164,6 +164,10 @@ int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, 
  *   its counter pair: the counts may mix, the results do not depend on them.  The choice makes the forward's last bits depend on
  *   timing: SEMIDETR_MSDA_FIXED_FORWARD (or policy 1) for bitwise reproducible forwards.
  * policy 1: always the patch kernel.   policy 2: the window kernel whenever it applies.   (Process-wide.)
+ * The encoder BACKWARD (four levels) reads the same slot: its small-gradient half runs as the lane-per-sample region-window gather
+ *   (msda_gw_d32; whole backward 572 / 635 / 796 us against 659 / 707 / 834 us at sigma 1 / 2 / 3 px, bs 4) while the slot's last
+ *   count has fewer than 45 % of the samples further than 4 px away (policy 2: always; policy 1 or no count yet: the patch gather).
+ *   grad_value's summation order is run-dependent either way (fp32 atomics); the two gathers agree to fp32 rounding.
  * If the device does not grant the window kernel its LDS (~150 KB per workgroup) the patch kernel runs instead.
  * semidetr_msda_forward_policy_state[_slot]: for the calling thread's current device and slot (0 without _slot) -- the policy,
  *   the kernel the adaptive policy stands on (0 patch, 1 window), the last far-sample fraction received (-1: none yet), the

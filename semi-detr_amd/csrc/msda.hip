@@ -431,12 +431,13 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 }
 
 // ---- which kernel runs the encoder self-attention forward: the patch kernel (msda_fwd_d32<1,4,408>) or the region-window
-//      kernel (msda_rw_d32, LDS windows).  The second is 7-17 % faster while the learned offsets keep most samples within
-//      a few pixels of their queries and slower once almost half of them are further than 4 px away (profiles/r04_region_window_dispatch.txt), so the choice
+//      kernel (msda_rw_d32, LDS windows +- 5 px around a region, five levels +- 4 px).  The second is ~30 % faster while the learned
+//      offsets keep most samples within a few pixels of their queries (sigma <= 2 px: 162 against 234 us at bs 4 inside the step) and slower
+//      once ~70 % of them are further than 4 px away (sigma ~5.5 px; profiles/r04_region_window_dispatch.txt), so the choice
 //      follows the DATA: both kernels count how far their samples reach (FwdStats, msda_fast.h), the count of launch k is
 //      handed to the host by the first thread of launch k + 1 through mapped pinned memory, and the dispatcher -- whenever it
-//      next gets here, it never waits -- moves between the kernels with hysteresis.  Per device; a mutex serialises the few
-//      host words.  semidetr_msda_set_forward_policy pins the choice (tests, A/B timing).
+//      next gets here, it never waits -- moves between the kernels with hysteresis.  Per (device, call-site slot); a mutex serialises
+//      the few host words.  semidetr_msda_set_forward_policy pins the choice (tests, A/B timing).
 // Thresholds re-measured with the 768 / 1024-thread window kernels (tools/archive/r04_rw_cross2.sh, rotated inputs, bs 4): four levels 233 /
 // 243 / 251 / 261 / 283 us against the patch kernel's 270-273 us at sigma 3.5 / 4 / 4.5 / 5 / 6 px -- level at ~5.5 px = a far share of
 // ~0.71; five levels level at ~5 px = ~0.67.  One image alone (616 regions x heads for 256 CUs) used to need its own, lower bound;

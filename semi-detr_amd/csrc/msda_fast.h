@@ -513,8 +513,9 @@ __device__ __forceinline__ int patch_query(const Patch &p, int r)      // r-th q
 // ---------------------------------------------------------------------------------------------
 // How far the samples of an encoder self-attention launch reach -- the statistic the dispatcher picks the forward kernel by
 // (msda.hip: launch_fast_forward).  The region-window kernel (msda_rw.h) serves the coarse levels' corners from LDS windows placed
-// +- 6 px around a region: 4-18 % faster than the patch kernel up to sigma ~3.5 px, level with it at 4 px, slower beyond
-// (profiles/r04_region_window_dispatch.txt).  Both kernels therefore count, in a few sampled workgroups,
+// +- 5 px (five levels: +- 4 px) around a region: ~30 % faster than the patch kernel at sigma <= 2 px (162 against 234 us at bs 4 inside
+// the step), level with it at sigma ~5.5 px = ~70 % of the samples further than 4 px away, slower beyond (the single source of
+// these numbers: profiles/r04_region_window_dispatch.txt).  Both kernels therefore count, in a few sampled workgroups,
 //     far   = samples on levels >= 1 more than kFarPx pixels (of the sampled level) from their query's own pixel centre
 //     total = samples on levels >= 1
 // into a device-side counter pair; the NEXT launch's first thread hands the finished pair to the host through mapped pinned

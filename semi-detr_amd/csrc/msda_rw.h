@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     const int m = (b % M + (b / M) / kRwHeadRun) % M;
     const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
     // how far the samples reach, for the dispatcher's choice between this kernel and the patch kernel (FwdStats, msda_fast.h):
-    // one workgroup in 128 counts (its first round: 64 queries x 12 samples; ~20 workgroups of a bs-4 launch), the launch's first
+    // one workgroup in 128 counts (its first round: G = NT / 8 queries x 12 samples; ~20 workgroups of a bs-4 launch), the launch's first
     // workgroup publishes the previous launch's pair
     const bool sampled = !GATHER && fs.cur != nullptr && (b & 127) == 1;
     unsigned st_far = 0, st_total = 0;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
 #pragma unroll
                 for (int p = 0; p < NPASS; ++p) sa[p] = sa[p] * inv;
             }
-            if (sampled && round == 0 && q >= 0) {     // (workgroup-uniform branch; the first round's 64 queries are sample enough --
+            if (sampled && round == 0 && q >= 0) {     // (workgroup-uniform branch; the first round's G queries are sample enough --
                                                        //  counting in every round made the sampled workgroups the launch's stragglers)
                 int lq = 0;                        // the query's own level: levels tile [0, S) in order
 #pragma unroll

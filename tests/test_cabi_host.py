@@ -61,10 +61,11 @@ def _kernel_metadata_counts(blob, key):
 
 
 def test_product_code_object_holds_only_reachable_msda_kernels():
-    """the product library's MSDA code object = the kernels its dispatcher can reach (35: forward patch /
+    """the product library's MSDA code object = the kernels its dispatcher can reach (38: forward patch /
     strips x 3 splits, region-window forward for four and for five levels (round 4), generic, gather x 3, region scatter,
     1024-thread merged level scatter x 2, strips backward x 2 -- each for the reference contract and the fused prologue,
-    + the two region-window instantiations that take the fused prologue's padding mask and the mask summary kernel (round 5),
+    + the two region-window instantiations that take the fused prologue's padding mask, the mask summary kernel and the
+    lane-per-sample window gather x 3 (round 5),
     + fp64 generic), none of the rejected experiments -- of msda_rw_d32 only the forward configurations the dispatcher
     launches."""
     import subprocess
