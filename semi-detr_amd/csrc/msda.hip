@@ -39,6 +39,18 @@
 #include "semidetr_hip_experiments.h"
 #endif
 
+#ifndef SEMIDETR_SCATTER_SW      // 1 (tuning builds): the cell-sorted scatter (msda_sw.h, measured and rejected) instead of the region scatter
+#define SEMIDETR_SCATTER_SW 0
+#endif
+#ifndef SEMIDETR_SW_NT
+#define SEMIDETR_SW_NT 512
+#define SEMIDETR_SW_Q 176
+#define SEMIDETR_SW_RTH 8
+#define SEMIDETR_SW_RTW 16
+#define SEMIDETR_SW_WH 24
+#define SEMIDETR_SW_WW 32
+#define SEMIDETR_SW_WPE 4
+#endif
 namespace {
 
 constexpr int kMaxLevels = 32;
@@ -326,6 +338,9 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
 #include "msda_region.h" // region-owned windowed scatter for encoder self-attention
 #include "msda_rw.h"     // region-window forward (product since round 4) / gather (experiments) for encoder self-attention
 #include "msda_gw.h"     // lane-per-sample region-window gather for the encoder backward (round 5)
+#if SEMIDETR_SCATTER_SW
+#include "msda_sw.h"     // cell-sorted region scatter (round 5): measured and rejected, tuning builds only (-DSEMIDETR_SCATTER_SW=1, tools/ab_build.sh)
+#endif
 #if SEMIDETR_EXPERIMENTS    // negative results kept as evidence: only in libsemidetr_hip_exp.so
 #include "msda_dest.h"   // destination-owned grad_value kernel for encoder self-attention
 #include "msda_lw.h"     // LDS-window forward for encoder self-attention
@@ -696,6 +711,20 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             hipLaunchKernelGGL((msda_bwd_gather_d32<IO, 0>), dim3((unsigned)((int64_t)N * gt * M)), dim3(256), glds, st,
                                grad_out, value, spatial_shapes, level_start, io, S, M, L, Lq, P, gt);
         if (int rc = semidetr::launch_status(window_gather ? "msda_gw_d32" : "msda_bwd_gather_d32")) return rc;
+#if SEMIDETR_SCATTER_SW
+        {
+            auto kern = &msda_sw_d32<IO, SEMIDETR_SW_NT, SEMIDETR_SW_Q, SEMIDETR_SW_RTH, SEMIDETR_SW_RTW, SEMIDETR_SW_WH, SEMIDETR_SW_WW, SEMIDETR_SW_WPE>;
+            constexpr size_t rlds = sw_lds_bytes<SEMIDETR_SW_NT, SEMIDETR_SW_Q, SEMIDETR_SW_WH, SEMIDETR_SW_WW>();
+            if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
+            const int rbound = (S * 3 / 4 + SEMIDETR_SW_RTH * SEMIDETR_SW_RTW - 1) / (SEMIDETR_SW_RTH * SEMIDETR_SW_RTW) * 9 / 8 + 4 * L;
+            const int64_t rgrid = (int64_t)N * rbound * M;
+            SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
+            hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(SEMIDETR_SW_NT), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L,
+                               rbound, grad_value);
+            g_last_kernels = window_gather ? "msda_gw_d32+msda_sw_d32" : "msda_bwd_gather_d32+msda_sw_d32";
+            return semidetr::launch_status("msda_sw_d32");
+        }
+#endif
         auto kern = &msda_bwd_scatter_d32_reg<IO, SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 8, 16, 24, 32, 0, SEMIDETR_SCATTER_WPE, SEMIDETR_SCATTER_WU>;
         const size_t rlds = reg_lds_bytes<SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 24, 32>();
         if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
