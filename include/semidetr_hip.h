@@ -72,7 +72,8 @@ const char *semidetr_last_error(void);
 /* The forward kernel is to be a function of the arguments alone: with the adaptive policy WHICH of the two encoder forward
  * kernels runs depends on when earlier launches' counts reached the host, and the two sum a row's samples in different orders
  * (results agree to ~2e-6 absolute, not bit for bit) -- two passes over identical inputs may then differ in the last bits,
- * which the reference's single kernel never does.  With this flag the patch kernel runs (the compiled front end sets it while
+ * which the reference's single kernel never does.  With this flag the patch kernel runs, and the backward's small-gradient half is
+ * the patch gather whatever the slot's counts say (the compiled front end sets it while
  * torch.use_deterministic_algorithms(True) is in force).  grad_value is accumulated with fp32 atomics either way, exactly as in
  * the reference (ms_deform_im2col_cuda.cuh:87-159): the BACKWARD's summation order is run-dependent there and here. */
 #define SEMIDETR_MSDA_FIXED_FORWARD 2

@@ -674,7 +674,8 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         SEMIDETR_REQUIRE((int64_t)N * std::max(gbound, gt) * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
         float4 *zero = fill_in_gather ? reinterpret_cast<float4 *>(grad_value) : nullptr;
         bool window_gather = false;
-        if (L == 4 && P == kPT && fill_in_gather && slot_samples_are_near((flags >> 8) & 0xff)) {
+        // (SEMIDETR_MSDA_FIXED_FORWARD: which gather runs must not depend on earlier launches either -- the patch gather)
+        if (L == 4 && P == kPT && fill_in_gather && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff)) {
             // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
             auto launch_gw = [&](auto kern) -> bool {
                 constexpr size_t wl = gw_lds_bytes<SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();

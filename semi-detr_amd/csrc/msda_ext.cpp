@@ -175,7 +175,7 @@ at::Tensor ms_deform_attn_forward(const at::Tensor &value, const at::Tensor &spa
 std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor &value, const at::Tensor &spatial_shapes,
                                                 const at::Tensor &level_start_index, const at::Tensor &sampling_loc,
                                                 const at::Tensor &attn_weight, const at::Tensor &grad_output,
-                                                int64_t im2col_step)
+                                                int64_t im2col_step, int64_t policy_slot)
 {
     const Dims d = op_dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
                            "ms_deform_attn_backward_cuda");
@@ -198,7 +198,7 @@ std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor &value, const a
     else
         rc = semidetr_msda_backward_f32(stream_of(value), grad_output.data_ptr<float>(), value.data_ptr<float>(), sh, ls,
                                         sampling_loc.data_ptr<float>(), attn_weight.data_ptr<float>(), d.N, d.S, d.M, d.D,
-                                        d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S),
+                                        d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S, policy_slot),
                                         gv.data_ptr<float>(), gl.data_ptr<float>(), ga.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_backward");
     return {gv, gl, ga};
@@ -345,7 +345,7 @@ std::vector<at::Tensor> ms_deform_attn_fused_backward(const at::Tensor &value, c
                                                       const at::Tensor &reference_points,
                                                       const at::Tensor &sampling_offsets, const at::Tensor &attn_logits,
                                                       const at::Tensor &grad_output,
-                                                      const c10::optional<at::Tensor> &padding_mask)
+                                                      const c10::optional<at::Tensor> &padding_mask, int64_t policy_slot)
 {
     const Dims d = fused_dims(value, spatial_shapes, level_start_index, reference_points, sampling_offsets, attn_logits);
     TORCH_CHECK(grad_output.is_contiguous() && grad_output.numel() == (int64_t)d.N * d.Lq * d.M * d.D &&
@@ -362,7 +362,7 @@ std::vector<at::Tensor> ms_deform_attn_fused_backward(const at::Tensor &value, c
         stream_of(value), grad_output.data_ptr<float>(), value.data_ptr<float>(), spatial_shapes.data_ptr<int64_t>(),
         level_start_index.data_ptr<int64_t>(), ref.data_ptr<float>(), (int)reference_points.size(-1),
         sampling_offsets.data_ptr<float>(), attn_logits.data_ptr<float>(), mask, mask ? ext.data_ptr<int>() : nullptr, d.N, d.S, d.M,
-        d.D, d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S), gv.data_ptr<float>(),
+        d.D, d.L, d.Lq, d.P, self_attention_flags(spatial_shapes, level_start_index, d.Lq, d.S, policy_slot), gv.data_ptr<float>(),
         go.data_ptr<float>(), gl.data_ptr<float>());
     check_rc(rc, "ms_deform_attn_fused_backward");
     return {gv, go, gl};
@@ -378,14 +378,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("ms_deform_attn_forward", &ms_deform_attn_forward, "ms_deform_attn_forward", py::arg("value"), py::arg("spatial_shapes"),
           py::arg("level_start_index"), py::arg("sampling_loc"), py::arg("attn_weight"), py::arg("im2col_step"),
           py::arg("policy_slot") = 0);
-    m.def("ms_deform_attn_backward", &ms_deform_attn_backward, "ms_deform_attn_backward");
+    m.def("ms_deform_attn_backward", &ms_deform_attn_backward, "ms_deform_attn_backward", py::arg("value"), py::arg("spatial_shapes"),
+          py::arg("level_start_index"), py::arg("sampling_loc"), py::arg("attn_weight"), py::arg("grad_output"), py::arg("im2col_step"),
+          py::arg("policy_slot") = 0);
     // additions
     m.def("ms_deform_attn_fused_forward", &ms_deform_attn_fused_forward, py::arg("value"), py::arg("spatial_shapes"),
           py::arg("level_start_index"), py::arg("reference_points"), py::arg("sampling_offsets"), py::arg("attn_logits"),
           py::arg("padding_mask") = py::none(), py::arg("policy_slot") = 0);
     m.def("ms_deform_attn_fused_backward", &ms_deform_attn_fused_backward, py::arg("value"), py::arg("spatial_shapes"),
           py::arg("level_start_index"), py::arg("reference_points"), py::arg("sampling_offsets"), py::arg("attn_logits"),
-          py::arg("grad_output"), py::arg("padding_mask") = py::none());
+          py::arg("grad_output"), py::arg("padding_mask") = py::none(), py::arg("policy_slot") = 0);
     m.def("fused_supported", &fused_supported);
     m.def("mask_extents", &mask_extents, py::arg("padding_mask"), py::arg("spatial_shapes"), py::arg("level_start_index"),
           "(N, L) int32 words vh | vw << 16: level l of image n is padded exactly on rows >= vh / columns >= vw, or -1.  Cached per "

@@ -21,6 +21,7 @@ class MSDeformAttnFunction(Function):
                 attention_weights, im2col_step, policy_slot=0):
         # policy_slot (optional, not in the reference's signature): the call site's slot of the encoder forward-kernel choice
         ctx.im2col_step = im2col_step
+        ctx.policy_slot = policy_slot
         output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                              sampling_locations, attention_weights, ctx.im2col_step, policy_slot)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -33,7 +34,7 @@ class MSDeformAttnFunction(Function):
         value, spatial_shapes, level_start_index, sampling_locations, attention_weights = ctx.saved_tensors
         grad_value, grad_sampling_loc, grad_attn_weight = MSDA.ms_deform_attn_backward(
             value, spatial_shapes, level_start_index, sampling_locations, attention_weights,
-            grad_output.contiguous(), ctx.im2col_step)
+            grad_output.contiguous(), ctx.im2col_step, ctx.policy_slot)
         return (grad_value, None, None, grad_sampling_loc, grad_attn_weight, None, None)[:len(ctx.needs_input_grad)]
 
 
@@ -50,6 +51,7 @@ class MSDeformAttnFusedFunction(Function):
                 padding_mask=None, policy_slot=0):
         if padding_mask is not None:
             padding_mask = padding_mask.contiguous()
+        ctx.policy_slot = policy_slot
         output = MSDA.ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points,
                                                    sampling_offsets, attn_logits, padding_mask, policy_slot)
         ctx.save_for_backward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
@@ -61,7 +63,7 @@ class MSDeformAttnFusedFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, starts, ref, off, logits, padding_mask = ctx.saved_tensors
         grad_value, grad_off, grad_logits = MSDA.ms_deform_attn_fused_backward(
-            value, shapes, starts, ref, off, logits, grad_output.contiguous(), padding_mask)
+            value, shapes, starts, ref, off, logits, grad_output.contiguous(), padding_mask, ctx.policy_slot)
         grad_ref = None
         if ctx.needs_input_grad[3]:
             # d loc / d ref: the chain rule through the (elementwise) location arithmetic, from grad_off

@@ -311,6 +311,65 @@ def test_adaptive_policy_is_kept_per_call_site():
     assert 1 <= a.policy_slot <= 255 and b.policy_slot == a.policy_slot % 255 + 1
 
 
+def test_module_steps_reach_the_window_kernels_under_the_default_policy():
+    """What a checkout with unchanged configs gets: two `MSDeformAttn` layers with the reference's call structure --
+    padding mask of a batch of differently sized images, valid-ratio scaled reference points -- stepped a few times under the
+    DEFAULT (adaptive) policy.  Each instance's own slot sees near samples, so after the counts of the first iterations have arrived
+    the forward is the region-window kernel and the backward's gather the lane-per-sample window gather; loss and parameter
+    gradients equal the patch kernels' (policy "patch") to fp32 rounding."""
+    import bench
+    import semi_detr_amd as sda
+    from semi_detr_amd import MSDeformAttn
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    layers = [MSDeformAttn(256, 4, 8, 4).to(dev) for _ in range(2)]
+    for m in layers:
+        with torch.no_grad():
+            m.sampling_offsets.weight.normal_(0, 0.005)
+            m.attention_weights.weight.normal_(0, 0.05)
+    n = 2
+    shapes, starts, src, pos, ref, mask = bench._encoder_inputs(dev, n, [(800, 1333), (704, 1066)])
+
+    def step():
+        for m in layers:
+            m.zero_grad()
+        x = src.detach().clone().requires_grad_(True)
+        y = x
+        kernels = []
+        for m in layers:
+            y = y + m(y + pos, ref, y, shapes, starts, mask)
+            kernels.append(_last())
+        loss = (y * y).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), [p.grad.clone() for m in layers for p in m.parameters()], kernels
+
+    sda._lib.set_forward_policy("adaptive")
+    for _ in range(4):
+        loss_a, grads_a, kern = step()
+    assert kern == ["msda_rw_d32", "msda_rw_d32"], kern
+    for m in layers:
+        st = sda._lib.forward_policy_state(m.policy_slot)
+        assert st["mode"] == 1 and 0.0 <= st["far_fraction"] < 0.45, st
+    # (the backward runs on the autograd thread and the kernel names are per thread: ask the op directly, with a layer's slot)
+    import MultiScaleDeformableAttention as MSDA
+    m0 = layers[0]
+    with torch.no_grad():
+        v = m0.value_proj(src).view(n, -1, 8, 32)
+        off = m0.sampling_offsets(src + pos).view(n, -1, 8, 4, 4, 2)
+        lg = m0.attention_weights(src + pos).view(n, -1, 8, 16)
+    MSDA.ms_deform_attn_fused_backward(v, shapes, starts, ref, off, lg, torch.ones(n, v.shape[1], 256, device=dev), mask, m0.policy_slot)
+    assert _last().startswith("msda_gw_d32+"), _last()
+    MSDA.ms_deform_attn_fused_backward(v, shapes, starts, ref, off, lg, torch.ones(n, v.shape[1], 256, device=dev), mask, 200)      # a slot nobody used
+    assert _last().startswith("msda_bwd_gather_d32+"), _last()
+    sda._lib.set_forward_policy("patch")
+    loss_p, grads_p, kern_p = step()
+    assert kern_p == ["msda_fwd_d32<1, 4, 408"] * 2, kern_p
+    assert abs(loss_a - loss_p) <= 1e-5 * max(1.0, abs(loss_p))
+    for ga, gp in zip(grads_a, grads_p):
+        torch.testing.assert_close(ga, gp, rtol=2e-3, atol=2e-5 * max(1.0, float(gp.abs().max())))
+
+
 def test_deterministic_algorithms_pin_the_forward_kernel():
     """torch.use_deterministic_algorithms(True): the front end asks for a forward kernel that does not depend on earlier launches
     (SEMIDETR_MSDA_FIXED_FORWARD) -- the patch kernel even under policy "window", and two passes over the same inputs
@@ -335,6 +394,20 @@ def test_deterministic_algorithms_pin_the_forward_kernel():
     for o in outs:
         assert torch.equal(o, o1)
     np.testing.assert_allclose(o_win.cpu().numpy(), o1.cpu().numpy(), rtol=0, atol=2e-6)
+    # ... and so is the backward's gather: the lane-per-sample window gather under policy "window", the patch gather (and bitwise equal
+    # small gradients from run to run) while deterministic algorithms are asked for
+    gout = _t(np.random.default_rng(5).random((2, value.shape[1], M * 32)).astype(np.float32))
+    sda._lib.set_forward_policy("window")
+    MSDA.ms_deform_attn_backward(*a[:5], gout, 64)
+    assert _last().startswith("msda_gw_d32+"), _last()
+    torch.use_deterministic_algorithms(True)
+    try:
+        g1 = MSDA.ms_deform_attn_backward(*a[:5], gout, 64)
+        assert _last().startswith("msda_bwd_gather_d32+"), _last()
+        g2 = MSDA.ms_deform_attn_backward(*a[:5], gout, 64)
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert torch.equal(g1[1], g2[1]) and torch.equal(g1[2], g2[2])
 
 
 @pytest.mark.parametrize("policy", ["window", "adaptive"])
