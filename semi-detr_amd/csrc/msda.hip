@@ -78,6 +78,12 @@ constexpr int kMaxLevels = 32;
 #ifndef SEMIDETR_SCATTER_NT
 #define SEMIDETR_SCATTER_NT 512    // (704 threads = one sample per thread, no half-empty second sample slot, two workgroups per CU:
 #endif                             //  encoder backward 726 against 678 us at bs 4 -- the third workgroup is worth more)
+#ifndef SEMIDETR_SCATTER_RTH     // region scatter: region (pixels of the finest level) and window per sampling level
+#define SEMIDETR_SCATTER_RTH 8
+#define SEMIDETR_SCATTER_RTW 16
+#define SEMIDETR_SCATTER_WH 24
+#define SEMIDETR_SCATTER_WW 32
+#endif
 #ifndef SEMIDETR_GW_NT           // msda_gw_d32 (lane-per-sample gather of the encoder backward): threads, region, margins of level 0 / the coarse levels
 #define SEMIDETR_GW_NT 768
 #define SEMIDETR_GW_RTH 16
@@ -95,6 +101,9 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_RW_NT 768       // msda_rw_d32: threads per workgroup.  Its windows take most of the LDS, so a CU holds ONE workgroup and
                                  // the workgroup's size is the CU's occupancy: 12 instead of 8 waves 192.9 -> 176.7 us inside the step
                                  // (1024 threads: only with margin 5 and 25 spilled registers so far, 262 us)
+#endif
+#ifndef SEMIDETR_RW_DBG
+#define SEMIDETR_RW_DBG 0        // timing aids of the four-level msda_rw_d32 (results wrong), tuning builds only: see msda_rw.h
 #endif
 #ifndef SEMIDETR_RW_TUNE
 #define SEMIDETR_RW_TUNE 1920    // msda_rw_d32: 10 x compute-loop samples between scheduling barriers (two: with four samples' LDS reads
@@ -608,14 +617,14 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
                 if constexpr (std::is_same<IO, RawIO>::value) {
                     if (io.has_mask()) {
                         if (L == 4)
-                            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE, true>,
+                            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE, true>,
                                                  wlds4, SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
                         return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5, true>, wlds5,
                                              SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5 * 16);
                     }
                 }
                 if (L == 4)
-                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, 0, SEMIDETR_RW_TUNE>, wlds4,
+                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE>, wlds4,
                                          SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
                 return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5,
                                      SEMIDETR_RW_RTH5 * 16);
@@ -660,7 +669,8 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                      "msda_backward: SEMIDETR_MSDA_QUERIES_ARE_PIXELS needs num_query == spatial_size");
     const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0 && (size_t)32 * (L * P + 1) * 32 <= 63 * 1024;
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
-    if (pixels && P == kPT && S < (1 << 23)) {
+    // (S * M * 128 < 2^32: the region scatter addresses grad_value rows by 32-bit byte offsets from the image's first row)
+    if (pixels && P == kPT && S < (1 << 23) && (uint64_t)S * M * kD * 4 < (1ull << 32)) {
         // ---- encoder self-attention: patch gather (the two small gradients; it clears grad_value as a side job, the
         //      scatter that accumulates into it is the NEXT launch) + region-owned scatter (msda_region.h)
         const bool fill_in_gather = (L * P == 16 || L * P == 20) && (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0;
@@ -726,10 +736,12 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             return semidetr::launch_status("msda_sw_d32");
         }
 #endif
-        auto kern = &msda_bwd_scatter_d32_reg<IO, SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 8, 16, 24, 32, 0, SEMIDETR_SCATTER_WPE, SEMIDETR_SCATTER_WU>;
-        const size_t rlds = reg_lds_bytes<SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, 24, 32>();
+        auto kern = &msda_bwd_scatter_d32_reg<IO, SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, SEMIDETR_SCATTER_RTH, SEMIDETR_SCATTER_RTW,
+                                              SEMIDETR_SCATTER_WH, SEMIDETR_SCATTER_WW, 0, SEMIDETR_SCATTER_WPE, SEMIDETR_SCATTER_WU>;
+        const size_t rlds = reg_lds_bytes<SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, SEMIDETR_SCATTER_WH, SEMIDETR_SCATTER_WW>();
         if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
-        const int rbound = (S + 127) / 128 * 5 / 4 + 4 * L;
+        constexpr int kRegPix = SEMIDETR_SCATTER_RTH * SEMIDETR_SCATTER_RTW;
+        const int rbound = (S + kRegPix - 1) / kRegPix * 5 / 4 + 4 * L;
         const int64_t rgrid = (int64_t)N * rbound * M;
         SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
         hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(SEMIDETR_SCATTER_NT), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L,

@@ -46,6 +46,15 @@ __device__ __forceinline__ void reg_scatter_body(
     // list on its own, as out-of-window corners always did.
     constexpr bool kPair = WU >= 1000;
     static_assert(!kPair || FUSE == 0, "the fused-backward experiment indexes one entry per corner");
+    // round 5: the entry word of the plain walk carries the destination as a PIXEL OFFSET from the window's first pixel (15 bits:
+    // (window row) * W + column) instead of the window row index the counting sort uses -- the flush then is one bit-field extract and
+    // one 24-bit multiply-add onto a per-level scalar base (global_atomic saddr form) instead of extract / multiply / extract / add /
+    // 64-bit multiply-add / 64-bit shift-add inside the divergent branch that 46 % of the walk's steps take.  A level too wide for
+    // 15 bits ((WH - 1) * W + WW > 32768, i.e. W > 1423) gets no window: all its corners take the one-by-one path (lvl_win below).
+    // (The paired and fused experiments decode window rows and keep the old word.)  Measured (same box, tools/r05_ab_kern.sh): the
+    // kernel without its row atomics 382 -> 328 us, with them 404 -> 398 us: it now runs at 89 % of what the atomic unit delivers
+    // (3.68 M rows at 10.4 G rows/s = 354 us) -- only fewer flushed rows make it faster.
+    constexpr bool kPixKey = !kPair && FUSE == 0;
     static_assert(kRegQ <= 512 && kWR <= (1 << 14), "entry packing: 9 bits query slot (x 128), 14 bits window row, sign bit = last");
     float2 *entries = reinterpret_cast<float2 *>(smem);   // [kNE + 8] front: bucketed {weight, last << 31 | window row << 16 | slot << 7};
                                                           // back: misses {weight, slot << 23 | pixel index}
@@ -251,7 +260,10 @@ __device__ __forceinline__ void reg_scatter_body(
                     s_lh[sp] = lh;
                     s_a[sp] = a;
                     const int wy = h0 - y0, wx = w0 - x0;
-                    const bool in_y0 = (unsigned)wy < (unsigned)WH, in_y1 = (unsigned)(wy + 1) < (unsigned)WH;
+                    // (kPixKey: a level so wide that a window's pixel offsets need more than 15 bits -- W > 1423 -- has no window: every
+                    //  corner takes the one-by-one path, correct and slow)
+                    const bool lvl_win = !kPixKey || (WH - 1) * W + WW <= 32768;
+                    const bool in_y0 = lvl_win && (unsigned)wy < (unsigned)WH, in_y1 = lvl_win && (unsigned)(wy + 1) < (unsigned)WH;
                     const bool in_x0 = (unsigned)wx < (unsigned)WW, in_x1 = (unsigned)(wx + 1) < (unsigned)WW;
                     s_wi[sp] = wy * WW + wx;
                     s_pix[sp] = st + h0 * W + w0;         // a corner that exists is this + (c & 1) + (c >> 1) * W
@@ -352,8 +364,10 @@ __device__ __forceinline__ void reg_scatter_body(
                         }
                         if ((s_fl[sp] & (17 << cidx)) == (17 << cidx)) {      // exists and inside the window
                             const int at = start[wr] + rank[sp][cidx];
+                            // kPixKey: the destination as pixel offset from the window's first pixel (see above)
+                            const int key = kPixKey ? s_pix[sp] - base_pix + (cidx & 1) + (cidx >> 1) * W : wr;
                             entries[at] = make_float2(
-                                cwv[cidx], __int_as_float((rank[sp][cidx] == cnt[wr] - 1 ? (int)0x80000000 : 0) | (wr << 16) | (i << 7)));
+                                cwv[cidx], __int_as_float((rank[sp][cidx] == cnt[wr] - 1 ? (int)0x80000000 : 0) | (key << 16) | (i << 7)));
                             rank[sp][cidx] = at;
                         }
                     }
@@ -448,9 +462,23 @@ __device__ __forceinline__ void reg_scatter_body(
                     // entry word: bit 31 = last of its row, bits 16..29 = window row, bits 7..15 = query slot * 128 (= the byte
                     // offset of the slot's grad_out row in gtile: one and-or gives the lane's address)
                     const char *gtb = reinterpret_cast<const char *>(gtile) + l16 * 8;
-                    auto gq_of = [&](float y) { return *reinterpret_cast<const float2 *>(gtb + (__float_as_int(y) & 0xff80)); };
+                    auto gq_of = [&](float y) {
+                        if ((AID & 256) != 0) return make_float2(y, 1.f);      // aid 256: no grad_out reads
+                        return *reinterpret_cast<const float2 *>(gtb + (__float_as_int(y) & 0xff80));
+                    };
                     float *gvs = gvalue + ((int64_t)n * S * M + m) * kD + l16;
-                    const int total = stats[3];
+                    // kPixKey: scalar base of the level's window (first pixel, this head; may lie before the map when the window hangs
+                    // over its edge -- only pixels inside the level are ever flushed) + a 32-bit byte offset per lane
+                    // (the flush takes the word's upper half as it is, last-of-row flag included: 0x8000 pixels are taken off the base)
+                    const uint64_t gwin_v = reinterpret_cast<uint64_t>(gvalue) + (uint64_t)((((int64_t)n * S + base_pix - 0x8000) * M + m) * kD * 4);
+                    const uint64_t gwin = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(gwin_v >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gwin_v);
+                    const unsigned rs4 = (unsigned)rs * 4u, lane4 = (unsigned)l16 * 4u;
+                    const uint64_t gimg_v = reinterpret_cast<uint64_t>(gvalue) + (uint64_t)(((int64_t)n * S * M + m) * kD * 4);      // image, head
+                    const uint64_t gimg = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(gimg_v >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gimg_v);
+                    (void)gimg;
+                    const int total = (AID & 64) ? 0 : stats[3];      // aid 64: no walk at all
                     // WU >= 100: shares start on even entries (16-byte aligned: two entries per ds_read_b128, which moves twice
                     // the bytes per LDS cycle of the ds_read2_b64 the compiler picks for single entries) and the entries of batch
                     // i + 1 are requested before batch i is processed
@@ -465,16 +493,25 @@ __device__ __forceinline__ void reg_scatter_body(
                     // branch, with every stream of the wavefront waiting on it)
                     auto flush = [&](int rowi) {
                         if (DBG && l16 == 0) SEMIDETR_DBG_ADD(12 + (l < 4 ? l : 3), 1);      // flushed rows by sampling level
-                        float *pr = gvs + (int64_t)(base_pix + (rowi / WW) * W + rowi % WW) * rs;
                         if ((AID & 2) && accv.x != 1.2345e30f) return;
-                        fp_atomic_add(pr, accv.x);
-                        fp_atomic_add(pr + 16, accv.y);
+                        if constexpr (kPixKey) {
+                            // byte offset of the lane's first channel from the window's first pixel: one 24-bit multiply-add; the two
+                            // half-line atomics take the scalar base (the instructions fp_atomic_add compiles to, saddr form)
+                            unsigned voff;
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(voff) : "v"(rowi | 0x8000), "s"(rs4), "v"(lane4));
+                            asm volatile("global_atomic_add_f32 %0, %1, %3\n\tglobal_atomic_add_f32 %0, %2, %3 offset:64"
+                                         :: "v"(voff), "v"(accv.x), "v"(accv.y), "s"(gwin) : "memory");
+                        } else {
+                            float *pr = gvs + (int64_t)(base_pix + (rowi / WW) * W + rowi % WW) * rs;
+                            fp_atomic_add(pr, accv.x);
+                            fp_atomic_add(pr + 16, accv.y);
+                        }
                     };
                     auto step = [&](const float2 &en, const float2 &gq) {
-                        const int pk = __float_as_int(en.y);
+                        const int pk = (AID & 128) ? (__float_as_int(en.y) & 0x7fffffff) : __float_as_int(en.y);      // aid 128: no row ever ends
                         accv.x += en.x * gq.x;
                         accv.y += en.x * gq.y;
-                        cur = (pk >> 16) & 0x3fff;
+                        cur = kPixKey ? (int)((unsigned)pk >> 16) : (pk >> 16) & 0x3fff;      // (kPixKey: bit 15 = the last-of-row flag, see flush)
                         if (pk < 0) {
                             flush(cur);
                             accv = make_float2(0.f, 0.f);
@@ -609,9 +646,15 @@ __device__ __forceinline__ void reg_scatter_body(
                         const float2 en = entries[kNE - 1 - mi];
                         const int pk = __float_as_int(en.y);
                         const float2 g2 = gt2[((unsigned)pk >> 23) * 16 + l16];
-                        float *pr = gvs + (int64_t)(pk & 0x7fffff) * rs;
-                        fp_atomic_add(pr, en.x * g2.x);
-                        fp_atomic_add(pr + 16, en.x * g2.y);
+                        if constexpr (kPixKey) {      // (in-image byte offsets fit 32 bits: checked by the launcher)
+                            const unsigned voff = (unsigned)(pk & 0x7fffff) * rs4 + lane4;
+                            asm volatile("global_atomic_add_f32 %0, %1, %3\n\tglobal_atomic_add_f32 %0, %2, %3 offset:64"
+                                         :: "v"(voff), "v"(en.x * g2.x), "v"(en.x * g2.y), "s"(gimg) : "memory");
+                        } else {
+                            float *pr = gvs + (int64_t)(pk & 0x7fffff) * rs;
+                            fp_atomic_add(pr, en.x * g2.x);
+                            fp_atomic_add(pr + 16, en.x * g2.y);
+                        }
                     }
                     if (DBG && tid == 0) SEMIDETR_DBG_ADD(10, nmiss);
                 }
@@ -673,7 +716,10 @@ __global__ __launch_bounds__(NT, WPE) void msda_bwd_scatter_d32_reg(
 {
     io.same_dims(S, M, L);
     extern __shared__ float4 smem[];
-    reg_scatter_body<IO, NT, kRegQ, RTH, RTW, WH, WW, DBG, WU>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L,
+#ifndef SEMIDETR_SCATTER_AID
+#define SEMIDETR_SCATTER_AID 0      // tuning builds (tools/ab_build.sh -DSEMIDETR_SCATTER_AID=...): timing aids of the walk, results wrong
+#endif
+    reg_scatter_body<IO, NT, kRegQ, RTH, RTW, WH, WW, DBG, WU, 0, SEMIDETR_SCATTER_AID>((int)blockIdx.x, smem, gout, shapes, starts, io, S, M, L,
                                                           regions_bound, gvalue);
 }
 

@@ -139,7 +139,8 @@ __device__ __forceinline__ void rw_fma4(float4 &acc, const float4 &w, const floa
 }
 
 // DBG (tuning builds only): 1 = per-phase cycle counts of wave 0 into g_dest_dbg, 2 = windows not staged (results
-// wrong, timing aid), 3 = compute loop skipped (results wrong, timing aid)
+// wrong, timing aid), 3 = compute loop skipped (results wrong, timing aid), 4 = out-of-window samples dropped, 5 = level-0 samples
+// (global loads) dropped, 7 = 3 + 5, 8 = 3 + 4 + 5 (what is left: staging, sampling-data loads, geometry, records, result stores)
 // TUNE = 100 * flags + 10 * (compute-loop samples between scheduling barriers) + (out-of-window samples per octet whose loads are
 //        issued ahead of the compute loop: with level 0 through global loads their slots need 64 more bytes per octet; measured level,
 //        0 in the product).  Flags (every combination gives the same results):
@@ -640,8 +641,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 allmask |= ((unsigned)(balv >> (lane & 56)) & 0xffu) << (8 * p);
                 n_out += __popcll(bal);
             }
-            const bool plain_round = n_out * 3 > 64 * NPASS;
+            const bool plain_round = n_out * 3 > 64 * NPASS && DBG != 4 && DBG != 8;
             if (plain_round) gmask = allmask;      // every sample of the round takes the global path below
+            if (DBG == 4 || DBG == 8) gmask = 0;
 
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             float m_a[NPASS], m_x[NPASS], m_y[NPASS];      // GATHER: d/d attn, d/d x, d/d y of my samples
@@ -770,9 +772,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     acc.w = fmaf(fw[i].w, fv[i][3].w, fmaf(fw[i].z, fv[i][2].w, fmaf(fw[i].y, fv[i][1].w, fmaf(fw[i].x, fv[i][0].w, acc.w))));
                 }
             };
-            if (FG) fine_issue(0);
+            constexpr bool kNoFine = DBG == 5 || DBG == 7 || DBG == 8;
+            constexpr bool kNoLoop = DBG == 3 || DBG == 7 || DBG == 8;
+            if (FG && !kNoFine) fine_issue(0);
             lap(6);                                // 6: next round's loads issued, masks, pre-issued corner loads
-            if (!plain_round && DBG != 3) {
+            if (!plain_round && !kNoLoop) {
                 // ---- the common case: every corner from LDS, in the order (top, sw), (top, !sw), (bottom, sw), (bottom, !sw)
 #pragma unroll
                 for (int k = FG ? P : 0; k < KLP; ++k) {
@@ -821,15 +825,15 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         // keep the scheduler from hoisting the whole unrolled loop's LDS reads (256 VGPRs and spills otherwise)
                         if (k % (kSB / 2 > 0 ? kSB / 2 : 1) == (kSB / 2 > 0 ? kSB / 2 : 1) - 1) __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (FG && (k - P) % kFineStep == kFineStep - 1 && (k - P) / kFineStep < kFineGroups - 1) {
+                    if (FG && !kNoFine && (k - P) % kFineStep == kFineStep - 1 && (k - P) / kFineStep < kFineGroups - 1) {
                         fine_consume();      // hand-over point of the level-0 samples: the group in flight is used, the next one issued
                         fine_issue(((k - P) / kFineStep + 1) * kFineN);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            if (FG) {
-                if (plain_round || DBG == 3) {      // the LDS loop (and its hand-over points) was skipped
+            if (FG && !kNoFine) {
+                if (plain_round || kNoLoop) {      // the LDS loop (and its hand-over points) was skipped
 #pragma unroll
                     for (int g = 1; g < kFineGroups; ++g) { fine_consume(); fine_issue(g * kFineN); }
                 }

@@ -121,6 +121,8 @@ def test_fast_path_generic_heads_levels_points(M, L, P):
     ([(9, 33), (5, 17), (3, 9), (2, 5), (1, 3)], 8, 4, "wide"), # five levels, samples partly outside
     ([(20, 27), (20, 27), (19, 26)], 4, 4, "near"),             # levels of (almost) equal size: a 16 x 16 region of the
                                                                 # finest level holds ~760 queries -> several passes
+    ([(2, 1500), (1, 750)], 2, 4, "near"),                      # a level wider than 1423 pixels: the region scatter's 15-bit pixel
+                                                                # offsets do not reach across its window -> one-by-one path (round 5)
 ])
 @pytest.mark.parametrize("variant", [(0, 0), (1, 32), (2, 832), (408, 64), (216, 65), (804, 66), (0, 67), (500, 70), (500, 71), (0, 68), (0, 69), (0, 690), (0, 697), (0, 698), (600, 0),
                                      (700, 7000), (701, 7001), (702, 7002), (703, 7003), (704, 7004), (705, 7005), (706, 7006), (720, 0), (723, 0), (0, 920), (0, 921), (0, 922), (0, 6900), (0, 6909), (0, 6983), (0, 6984), (734, 0), (742, 0), (748, 0), (741, 0)],
