@@ -56,7 +56,7 @@ const char *semidetr_last_error(void);
  * `flags` (f32 entry points): SEMIDETR_MSDA_QUERIES_ARE_PIXELS tells the library that this is encoder
  * self-attention -- num_query == spatial_size, query i IS pixel i of the pyramid, and spatial_shapes /
  * level_start tile [0, spatial_size) exactly (level_start[l+1] == level_start[l] + H_l*W_l, sum H_l*W_l ==
- * spatial_size).  The level table lives in device memory, so the library cannot verify this without a
+ * spatial_size), with every H_l, W_l <= 32766.  The level table lives in device memory, so the library cannot verify this without a
  * host synchronisation: the CALLER vouches for it (the Python / pybind layer checks it once per
  * spatial_shapes tensor).  With the flag the forward / gather kernels take 2-D pixel patches and
  * grad_value is produced by the region-owned scatter kernel; without it every query set takes the strip

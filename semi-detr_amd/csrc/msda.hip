@@ -106,12 +106,19 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_RW_DBG 0        // timing aids of the four-level msda_rw_d32 (results wrong), tuning builds only: see msda_rw.h
 #endif
 #ifndef SEMIDETR_RW_TUNE
-#define SEMIDETR_RW_TUNE 1920    // msda_rw_d32: 10 x compute-loop samples between scheduling barriers (two: with four samples' LDS reads
+#define SEMIDETR_RW_TUNE 47120   // (round 5: + 6400 level constants from an LDS table, + 12800 region query list in LDS, + 25600 compact records for
+                                 //  out-of-window samples, + 400 one such sample per octet and trip -- the geometry of a round 284 -> ~130 VALU
+                                 //  instructions, no publish step: probe (tools/r05_ab_fwd.sh, medians of 5) 169.1 -> 164.4 us at sigma 1 px,
+                                 //  179.4 -> 172.7 at 2 px, 202.3 -> 190.1 at 3 px)
+                                 // 1920 = msda_rw_d32: 10 x compute-loop samples between scheduling barriers (two: with four samples' LDS reads
                                  // in flight round 4's first version spilled; one: 2 us slower) + 100: one level-0 sample's corner loads in
                                  // flight instead of two (-33 VGPRs) + 200: level constants re-selected where they are used and staging
                                  // coordinates rebuilt per region instead of living in registers (256 -> 160 VGPRs: what lets 768 threads run)
                                  // + 1600: the fused prologue's location arithmetic at the start of the round that uses the loaded data, not
                                  // where the loads are issued (a round early, waiting for them): fused-prologue forward 189.8 -> 188.0 us
+#endif
+#ifndef SEMIDETR_RW_TUNE_MASK
+#define SEMIDETR_RW_TUNE_MASK 47120   // the instantiation with the padding mask (166 VGPRs; with the table but without the compact records it spills)
 #endif
 #ifndef SEMIDETR_RW_RTH
 #define SEMIDETR_RW_RTH 25       // msda_rw_d32, four levels: LARGEST region height (x 16 columns; the grid is tiled evenly, msda_rw.h) and coarse-level
@@ -612,13 +619,16 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
                 return semidetr::launch_status("msda_rw_d32<forward>");
             };
             auto pick_window = [&]() -> int {
-                constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5>();
+                constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, SEMIDETR_RW_TUNE>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, SEMIDETR_RW_TUNE5>();
                 static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
                 if constexpr (std::is_same<IO, RawIO>::value) {
                     if (io.has_mask()) {
-                        if (L == 4)
-                            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE, true>,
-                                                 wlds4, SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
+                        if (L == 4) {
+                            constexpr size_t wlds4m = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, SEMIDETR_RW_TUNE_MASK>();
+                            static_assert(wlds4m <= 160 * 1024, "region-window configuration does not fit the LDS");
+                            return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE_MASK, true>,
+                                                 wlds4m, SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
+                        }
                         return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5, true>, wlds5,
                                              SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5 * 16);
                     }

@@ -122,7 +122,8 @@ int pyramid_check(const at::Tensor &shapes, const at::Tensor &starts, int64_t S)
     int64_t sum = 0;
     bool tiles = true;
     for (int64_t l = 0; l < hs.size(0); ++l) {
-        tiles = tiles && pl[l] == sum && ps[2 * l] > 0 && ps[2 * l + 1] > 0;
+        // (height / width <= 32766: the region-window forward packs a sample's top-left pixel into 15 + 15 bits, semidetr_hip.h)
+        tiles = tiles && pl[l] == sum && ps[2 * l] > 0 && ps[2 * l + 1] > 0 && ps[2 * l] <= 32766 && ps[2 * l + 1] <= 32766;
         sum += ps[2 * l] * ps[2 * l + 1];
     }
     const int result = (sum == S ? 1 : 0) | (tiles && sum == S ? 2 : 0);

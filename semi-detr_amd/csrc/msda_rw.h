@@ -88,10 +88,12 @@ constexpr int rw_oct_bytes()      // per octet: {float4 record} and {two 16-bit 
 // compares per row / corner; a level without one (vh < 0) reads the mask's bytes: beside the staging loads for the windows (no
 // dependent load), from global memory for level-0 corners and out-of-window samples (correct for any mask; only the summarised
 // form is fast).
+constexpr int kRwQList = 1024;      // TUNE + 12800: slots of the region's query list in LDS (regions with more queries work them out per round)
 template <int NT, int RTH, int RTW, int H0, int HC, int KL, int TUNE = 0>
 constexpr size_t rw_lds_bytes()
 {
-    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)(NT / 8) * rw_oct_bytes<KL, (H0 < 0), (TUNE % 10 > 0)>();
+    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)(NT / 8) * rw_oct_bytes<KL, (H0 < 0), (TUNE % 10 > 0)>() +
+           (((TUNE / 100) & 64) ? (size_t)(KL + 1) * 48 : 0) + (((TUNE / 100) & 128) ? (size_t)kRwQList * 4 : 0);
 }
 
 // smallest q in [0, nq] with ((2 q + 1) * nb) / (2 * nq) >= bound  (the first pixel of a level with nq rows whose centre
@@ -151,6 +153,16 @@ __device__ __forceinline__ void rw_fma4(float4 &acc, const float4 &w, const floa
 //             reciprocals of the region grid) rebuilt per round / region through an empty asm: what fits 1024 threads into 128 VGPRs
 //         16  the prefetched sampling data stay as loaded; the fused prologue's location arithmetic runs in the consuming round
 //         32  window addresses by v_mad_u32_u16, packed FMAs with explicit op_sel (measured level; experiments)
+//         64  (round 5, with 2 and 16) the per-lane level constants of the geometry come from a 48-byte-per-level table in LDS, three
+//             ds_read_b128 per pass, instead of one v_mov + v_cndmask pair per constant (gfx950 VALU instructions take ONE scalar
+//             operand, so "select between two wave-uniform values" is two instructions: 100 of the ~300 the geometry of a round took)
+//        256  (with 64; forward) COMPACT records for out-of-window samples: where the geometry finds a sample outside its window it
+//             writes {lw, lh, attention, top-left pixel} into the sample's own weight record (its rows are the zero rows, so the LDS
+//             loop adds 0 x finite), and the out-of-window loop builds the four corner offsets from that and the level table on all
+//             eight lanes -- instead of the owner lane redoing the whole geometry from (x, y) inside a branch (publish), a slot write,
+//             a wait and a slot read per sample.  The sampling data (x, y, attention of both passes) die before the LDS loop.
+//        128  the region's query list (slot -> query) is worked out once per region into LDS; a round reads its slot instead of
+//             redoing the level search, five shuffles and a division (~35 instructions and 7 ds_bpermute per round)
 //        Product: 1920 = 16 + 2 + 1, two samples per barrier (four levels); 1110 = 8 + 2 + 1, one sample per barrier (five levels).
 template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GATHER, int DBG = 0, int TUNE = 42, bool MASK = false>
 __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(      // 256-thread workgroups: two per CU
@@ -174,6 +186,13 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     extern __shared__ float4 smem[];
     char *const lds = reinterpret_cast<char *>(smem);
     char *const recs = lds + Wn::total * 128;
+    constexpr bool kTab = ((TUNE / 100) & 64) != 0, kQList = ((TUNE / 100) & 128) != 0, kCompact = ((TUNE / 100) & 256) != 0;
+    static_assert(!kCompact || (kTab && !GATHER && TUNE % 10 == 0), "compact out-of-window records: forward, level table, nothing pre-issued");
+    static_assert(!kTab || (((TUNE / 100) & 2) && ((TUNE / 100) & 16) && !GATHER && H0 < 0), "the level table serves the lean forward with split loads");
+    // level table: per level {H, W, start, window row0 | window rows - 1, window columns - 1, window pitch, window origin y |
+    //                          window origin x, (float)H, (float)W, -}; then the query list
+    int4 *const ltab = reinterpret_cast<int4 *>(recs + (NT / 8) * kOctBytes);
+    int *const qlist = reinterpret_cast<int *>(recs + (NT / 8) * kOctBytes + (kTab ? (KL + 1) * 48 : 0));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int oc = tid >> 3, j8 = tid & 7;
@@ -400,9 +419,12 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 rx[p] = ry[p] = ra[p] = 0.f;
                 if (qq >= 0 && k < KLP) {
                     const int64_t nq = (int64_t)n * Lq + qq, row = nq * M + m;
-                    const LvlC c = lvlc(p);
-                    if constexpr (kSplitLoad) rr[p] = io.load_xy_raw(row, nq, KLP, k, c.l);
-                    else io.load_xy(row, nq, KLP, k, c.l, P, c.H, c.W, rx[p], ry[p]);
+                    if constexpr (kSplitLoad) {
+                        rr[p] = io.load_xy_raw(row, nq, KLP, k, k / P);
+                    } else {
+                        const LvlC c = lvlc(p);
+                        io.load_xy(row, nq, KLP, k, c.l, P, c.H, c.W, rx[p], ry[p]);
+                    }
                     ra[p] = io.load_w(row, KLP, k);
                 }
             }
@@ -477,6 +499,20 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 if (kLean) asm volatile("" : "+v"(z));      // (a zero the compiler cannot keep in four registers for the whole kernel)
                 *reinterpret_cast<float4 *>(lds + kZ0 + ocs * 128 + j8s * 16) = make_float4(z, z, z, z);
             }
+            if constexpr (kTab) {      // lanes 0 .. KL-1 of the first wave hold level `lane`'s constants and this region's window origin
+                if (tids < KL) {
+                    ltab[tids * 3 + 0] = make_int4(r_H, r_W, r_st, r_row0);
+                    ltab[tids * 3 + 1] = make_int4(r_wh - 1, r_ww - 1, r_ww, r_wy0);
+                    ltab[tids * 3 + 2] = make_int4(r_wx0, __float_as_int((float)r_H), __float_as_int((float)r_W), 0);
+                }
+            }
+            if constexpr (kQList) {    // (every lane runs slot_query: its shuffles read lanes 0 .. KL-1)
+                const int lim = min(nq_total, kRwQList);
+                for (int s0 = 0; s0 < lim; s0 += NT) {
+                    const int qv = slot_query(s0 + tids);
+                    if (s0 + tids < lim) qlist[s0 + tids] = qv;
+                }
+            }
         }
         lap(3);                            // 3: windows stored (incl. the wait for the staging loads)
         __syncthreads();                   // the windows are complete
@@ -500,9 +536,19 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             float sx[NPASS], sy[NPASS], sa[NPASS];
             const float4 mygo = go;
             unsigned fbm = 0;                     // bit p: my sample of pass p is valid but leaves its window
+            // kTab: the constants of my two levels (lanes 0-3: level 2 p, lanes 4-7: level 2 p + 1; the table is padded to an even count)
+            // (each pass reads them where it starts: held for both passes from the round's top they cost 24 registers)
+            int4 T0[NPASS], T1[NPASS], T2[NPASS];
+            const int4 *const te = ltab + (j8 >> 2) * 3;
+            auto lvlt = [&](int p) -> LvlC {      // lvlc(p) from the table
+                if constexpr (kTab) return LvlC{min((j8 + 8 * p) / P, KL - 1), T0[p].x, T0[p].y, T0[p].z, T1[p].x, T1[p].y, T1[p].z, T0[p].w};
+                else return lvlc(p);
+            };
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
-                if constexpr (kSplitLoad) {
+                if constexpr (kTab) {
+                    sx[p] = sy[p] = 0.f;          // (finished in the geometry loop, beside the table reads)
+                } else if constexpr (kSplitLoad) {
                     sx[p] = sy[p] = 0.f;
                     if (q >= 0 && j8 + 8 * p < KLP) {
                         const LvlC c = lvlc(p);
@@ -547,18 +593,31 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 for (int p = 0; p < NPASS; ++p) {
                     const LvlC c = lvlc(p);
                     if (j8 + 8 * p < KLP && c.l >= 1) {
+                        float fx = sx[p], fy = sy[p];
+                        if constexpr (kTab) io.finish_xy_raw(rr[p], P, c.H, c.W, fx, fy);      // (not finished yet, see above)
                         st_total += 1u;
-                        st_far += (fabsf((sx[p] - cx) * (float)c.W) > kFarPx || fabsf((sy[p] - cy) * (float)c.H) > kFarPx) ? 1u : 0u;
+                        st_far += (fabsf((fx - cx) * (float)c.W) > kFarPx || fabsf((fy - cy) * (float)c.H) > kFarPx) ? 1u : 0u;
                     }
                 }
             }
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
                 const int k = j8 + 8 * p;
-                const LvlC c = lvlc(p);
+                if constexpr (kTab) {
+                    T0[p] = te[6 * p + 0];
+                    T1[p] = te[6 * p + 1];
+                    T2[p] = te[6 * p + 2];
+                    if (q >= 0 && k < KLP) io.finish_xy_raw(rr[p], P, T0[p].x, T0[p].y, sx[p], sy[p]);
+                }
+                const LvlC c = lvlt(p);
                 int c_wy0, c_wx0;
-                win_origin(p, c.l, c_wy0, c_wx0);
-                const float Hf = (float)c.H, Wf = (float)c.W;
+                if constexpr (kTab) {
+                    c_wy0 = T1[p].w;
+                    c_wx0 = T2[p].x;
+                } else {
+                    win_origin(p, c.l, c_wy0, c_wx0);
+                }
+                const float Hf = kTab ? __int_as_float(T2[p].y) : (float)c.H, Wf = kTab ? __int_as_float(T2[p].z) : (float)c.W;
                 const float h = sub_rn(mul_rn(sy[p], Hf), 0.5f), w = sub_rn(mul_rn(sx[p], Wf), 0.5f);
                 const bool inside = q >= 0 && k < KLP && h > -1.f && w > -1.f && h < Hf && w < Wf;
                 const float h0f = floorf(h), w0f = floorf(w);
@@ -616,6 +675,14 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         // weights in reading order: top sw, top !sw, bottom sw, bottom !sw
                         *reinterpret_cast<float4 *>(orec + (k - kRec0) * 16) = sw ? make_float4(wr_t, wl_t, wr_b, wl_b)
                                                                         : make_float4(wl_t, wr_t, wl_b, wr_b);
+                        if constexpr (kCompact) {
+                            // a sample outside its window reads the zero rows, so its record only has to be finite: overwritten (same
+                            // lane, same address, program order) with the compact form {lw, lh, a, (h0 + 1) | (w0 + 1) << 15} -- an
+                            // integer below 2^30 is a finite float.  Waves without such a sample skip the branch.
+                            if (inside && !inwin)
+                                *reinterpret_cast<float4 *>(orec + (k - kRec0) * 16) =
+                                    make_float4(lw, lh, a, __int_as_float(((int)h0f + 1) | (((int)w0f + 1) << 15)));
+                        }
                     } else {
                         // a NaN location must not leak through 0 * NaN: everything zero unless served from the window
                         *reinterpret_cast<float4 *>(orec + (k - kRec0) * 16) =
@@ -626,7 +693,12 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             const int q_cur = q;
             lap(5);                                // 5: geometry + record writes (incl. the wait for the round's raw data)
             // ---- next round's raw data (its latency hides behind this round's compute)
-            q = slot_query((round + 1) * G + oc);
+            if (kQList && nq_total <= kRwQList) {      // (workgroup-uniform)
+                const int sn = (round + 1) * G + oc;
+                q = sn < nq_total ? qlist[sn] : -1;
+            } else {
+                q = slot_query((round + 1) * G + oc);
+            }
             if (round + 1 < nrounds) load_round(q, j8);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my wave's records are written
 
@@ -644,6 +716,25 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             const bool plain_round = n_out * 3 > 64 * NPASS && DBG != 4 && DBG != 8;
             if (plain_round) gmask = allmask;      // every sample of the round takes the global path below
             if (DBG == 4 || DBG == 8) gmask = 0;
+            if constexpr (kCompact) {
+                if (plain_round) {      // (wave-uniform, rare) the records of the samples INSIDE their windows are in window form: redo them compact
+#pragma unroll
+                    for (int p = 0; p < NPASS; ++p) {
+                        const int k = j8 + 8 * p;
+                        if (q_cur >= 0 && k < KLP && !(FG && k < P)) {
+                            const int4 t0 = te[6 * p + 0];
+                            const float Hf = (float)t0.x, Wf = (float)t0.y;
+                            const float h = sub_rn(mul_rn(sy[p], Hf), 0.5f), w = sub_rn(mul_rn(sx[p], Wf), 0.5f);
+                            const bool inside = h > -1.f && w > -1.f && h < Hf && w < Wf;
+                            const float h0f = floorf(h), w0f = floorf(w);
+                            *reinterpret_cast<float4 *>(orec + (k - kRec0) * 16) =
+                                inside ? make_float4(sub_rn(w, w0f), sub_rn(h, h0f), sa[p], __int_as_float(((int)h0f + 1) | (((int)w0f + 1) << 15)))
+                                       : make_float4(0.f, 0.f, 0.f, __int_as_float(0x40000000));      // (bit 30: no sample; the float 2.0)
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
 
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             float m_a[NPASS], m_x[NPASS], m_y[NPASS];      // GATHER: d/d attn, d/d x, d/d y of my samples
@@ -686,14 +777,23 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     unsigned off[4];
                     float lw, lh;
                     float px_ = sx[0], py_ = sy[0], a_ = sa[0];
-                    const LvlC c0 = lvlc(0);
-                    int H_ = c0.H, W_ = c0.W, st_ = c0.st;
+                    int H_, W_, st_;
+                    if constexpr (kTab) {      // (the table entry of sample k's level: one read; a select over the passes' copies becomes a scratch array)
+                        const int4 t0 = ltab[min(k / P, KL - 1) * 3];
+                        H_ = t0.x; W_ = t0.y; st_ = t0.z;
 #pragma unroll
-                    for (int pp = 1; pp < NPASS; ++pp)
-                        if (p == pp) {
-                            const LvlC c = lvlc(pp);
-                            px_ = sx[pp]; py_ = sy[pp]; a_ = sa[pp]; H_ = c.H; W_ = c.W; st_ = c.st;
-                        }
+                        for (int pp = 1; pp < NPASS; ++pp)
+                            if (p == pp) { px_ = sx[pp]; py_ = sy[pp]; a_ = sa[pp]; }
+                    } else {
+                        const LvlC c0 = lvlc(0);
+                        H_ = c0.H; W_ = c0.W; st_ = c0.st;
+#pragma unroll
+                        for (int pp = 1; pp < NPASS; ++pp)
+                            if (p == pp) {
+                                const LvlC c = lvlc(pp);
+                                px_ = sx[pp]; py_ = sy[pp]; a_ = sa[pp]; H_ = c.H; W_ = c.W; st_ = c.st;
+                            }
+                    }
                     sample_setup_oob(px_, py_, H_, W_, st_, row_bytes, off, lw, lh);
                     if constexpr (MASK) mask_corners_oob(io, pme, n, px_, py_, H_, W_, st_, off);
                     *reinterpret_cast<uint4 *>(orec + kSlotAt + 32 * sl) = make_uint4(off[0], off[1], off[2], off[3]);
@@ -861,6 +961,56 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 constexpr int kTrip = ((TUNE / 100) & 4) ? 1 : 2;      // <= the octet's slots (four per trip measured no better: 222 vs 216 us; TUNE + 400: one, 20 VGPRs less)
                 bool act2[kTrip];
                 int k2[kTrip];
+                if constexpr (kCompact) {
+                    // the sample's compact record + its level's table entry -> four corner offsets, on all eight lanes alike
+                    float4 g2[kTrip], v2[kTrip][4];
+                    int4 tl[kTrip];
+#pragma unroll
+                    for (int i = 0; i < kTrip; ++i) {
+                        act2[i] = gmask != 0;
+                        k2[i] = act2[i] ? __ffs((int)gmask) - 1 : kRec0;
+                        gmask &= gmask - 1;
+                        g2[i] = *reinterpret_cast<const float4 *>(orec + (k2[i] - kRec0) * 16);
+                        tl[i] = ltab[(k2[i] / P) * 3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < kTrip; ++i) {
+                        const int pk = __float_as_int(g2[i].w);
+                        const int h0 = (pk & 0x7fff) - 1, w0 = ((pk >> 15) & 0x7fff) - 1, H_ = tl[i].x, W_ = tl[i].y;
+                        const bool ok = act2[i] && !(pk >> 30);
+                        const bool top = h0 >= 0, bot = h0 + 1 <= H_ - 1, lef = w0 >= 0, rig = w0 + 1 <= W_ - 1;
+                        bool c_tl = ok && top && lef, c_tr = ok && top && rig, c_bl = ok && bot && lef, c_br = ok && bot && rig;
+                        const int pix = tl[i].z + h0 * W_ + w0;
+                        if constexpr (MASK) {      // padded corners read as zero (the level's summary, or its bytes)
+                            int ve = ves[0];
+#pragma unroll
+                            for (int l = 1; l < KL; ++l) ve = (k2[i] / P) == l ? ves[l] : ve;
+                            const int vh = ext_vh(ve), vw = ext_vw(ve);
+                            if (vh >= 0) {
+                                const bool py0 = h0 >= vh, py1 = h0 + 1 >= vh, px0 = w0 >= vw, px1 = w0 + 1 >= vw;
+                                c_tl = c_tl && !(py0 || px0);
+                                c_tr = c_tr && !(py0 || px1);
+                                c_bl = c_bl && !(py1 || px0);
+                                c_br = c_br && !(py1 || px1);
+                            } else {
+                                const unsigned char *gp = mask_of_image() + pix;
+                                c_tl = c_tl && !gp[0];      // (left to right: a corner outside the level is never dereferenced)
+                                c_tr = c_tr && !gp[1];
+                                c_bl = c_bl && !gp[W_];
+                                c_br = c_br && !gp[W_ + 1];
+                            }
+                        }
+                        const unsigned base = (unsigned)pix * row_bytes + lane_b, wrow = (unsigned)W_ * row_bytes;      // (may wrap for -1: unused then)
+                        v2[i][0] = buf_ld4(vr, c_tl ? base : kOob);
+                        v2[i][1] = buf_ld4(vr, c_tr ? base + row_bytes : kOob);
+                        v2[i][2] = buf_ld4(vr, c_bl ? base + wrow : kOob);
+                        v2[i][3] = buf_ld4(vr, c_br ? base + wrow + row_bytes : kOob);
+                    }
+#pragma unroll
+                    for (int i = 0; i < kTrip; ++i)
+                        if (act2[i]) consume_fwd(g2[i], v2[i][0], v2[i][1], v2[i][2], v2[i][3]);
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < kTrip; ++i) {
                     act2[i] = gmask != 0;
