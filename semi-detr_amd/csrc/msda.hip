@@ -102,14 +102,17 @@ constexpr int kMaxLevels = 32;
                                  // the workgroup's size is the CU's occupancy: 12 instead of 8 waves 192.9 -> 176.7 us inside the step
                                  // (1024 threads: only with margin 5 and 25 spilled registers so far, 262 us)
 #endif
+#ifndef SEMIDETR_RW_TAIL
+#define SEMIDETR_RW_TAIL 1       // msda_rw_d32 forward: tail split (helper workgroups for the last, partly filled wave of workgroups)
+#endif
 #ifndef SEMIDETR_RW_DBG
 #define SEMIDETR_RW_DBG 0        // timing aids of the four-level msda_rw_d32 (results wrong), tuning builds only: see msda_rw.h
 #endif
 #ifndef SEMIDETR_RW_TUNE
-#define SEMIDETR_RW_TUNE 47120   // (round 5: + 6400 level constants from an LDS table, + 12800 region query list in LDS, + 25600 compact records for
+#define SEMIDETR_RW_TUNE 98320   // (round 5: + 6400 level constants from an LDS table, + 12800 region query list in LDS, + 25600 compact records for
                                  //  out-of-window samples, + 400 one such sample per octet and trip -- the geometry of a round 284 -> ~130 VALU
                                  //  instructions, no publish step: probe (tools/r05_ab_fwd.sh, medians of 5) 169.1 -> 164.4 us at sigma 1 px,
-                                 //  179.4 -> 172.7 at 2 px, 202.3 -> 190.1 at 3 px)
+                                 //  179.4 -> 172.7 at 2 px, 202.3 -> 190.1 at 3 px; + 51200 window offsets as two 32-bit byte offsets: another -1 %)
                                  // 1920 = msda_rw_d32: 10 x compute-loop samples between scheduling barriers (two: with four samples' LDS reads
                                  // in flight round 4's first version spilled; one: 2 us slower) + 100: one level-0 sample's corner loads in
                                  // flight instead of two (-33 VGPRs) + 200: level constants re-selected where they are used and staging
@@ -118,7 +121,7 @@ constexpr int kMaxLevels = 32;
                                  // where the loads are issued (a round early, waiting for them): fused-prologue forward 189.8 -> 188.0 us
 #endif
 #ifndef SEMIDETR_RW_TUNE_MASK
-#define SEMIDETR_RW_TUNE_MASK 47120   // the instantiation with the padding mask (166 VGPRs; with the table but without the compact records it spills)
+#define SEMIDETR_RW_TUNE_MASK 98320   // the instantiation with the padding mask (166 VGPRs; with the table but without the compact records it spills)
 #endif
 #ifndef SEMIDETR_RW_RTH
 #define SEMIDETR_RW_RTH 25       // msda_rw_d32, four levels: LARGEST region height (x 16 columns; the grid is tiled evenly, msda_rw.h) and coarse-level
@@ -137,7 +140,12 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_RW_NT5 960      // ... the five-level instantiation: margin 4 is what fits either way; 24 x 16 regions like the four-level one, and the
                                  //     largest workgroup that fits beside their windows: 15 waves (16 x 16 / 1024 threads: 202 / 209 / 243 us at sigma 1 /
                                  //     2 / 3 px, 24 x 16 / 960: 195 / 204 / 241, / 896: 190 / 204 / 242)
-#define SEMIDETR_RW_TUNE5 1110   //     (16 waves per CU, 128 VGPRs): ONE sample between scheduling barriers (three passes of samples per lane) and
+#define SEMIDETR_RW_TUNE5 47910  // (round 5: as four levels -- split loads, level table, query list, compact records, one out-of-window sample per trip;
+                                 //  the wide window offsets do not fit beside 120 octets' records.  The fused prologue keeps round 4's configuration (with table +
+                                 //  query list it spills at 128 registers): SEMIDETR_RW_TUNE5_RAW / _MASK)
+#define SEMIDETR_RW_TUNE5_RAW 1110
+#define SEMIDETR_RW_TUNE5_MASK 1110
+                                 // 1110 =     (16 waves per CU, 128 VGPRs): ONE sample between scheduling barriers (three passes of samples per lane) and
                                  //     + 800: everything derived from the thread index rebuilt per round / region.  768 threads: 223 / 232 / 273 us
                                  //     at sigma 1 / 2 / 3 px, 1024: 208 / 225 / 255.  (Four levels at 1024 threads would have to give up margin 6
                                  //     for 5: 206 against 205 us -- no gain.)
@@ -499,6 +507,21 @@ FwdAdapt *g_adapt[kMaxDevices];            // allocated at a device's first adap
 std::atomic<int> g_fwd_policy{0};          // 0 adaptive, 1 always the patch kernel, 2 the window kernel whenever it applies
 
 // the launch's FwdStats and the kernel to use; called with the stream the launch goes to
+// compute units of the current device (cached per device index; 0 if the runtime will not say: the callers then do without)
+int device_cus()
+{
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        int v = 0;
+        c = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : -1;
+        cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c > 0 ? c : 0;
+}
+
 int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, FwdStats &fs, bool &use_window)
 {
     fs = FwdStats{nullptr, nullptr, nullptr, nullptr};
@@ -604,22 +627,31 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             //                sigma 2 px: 239 / 231 / 219-229 us, at 3 px: 290 / 265 / 252 us with 512 threads; SEMIDETR_RW_RTH above)
             //   five levels: 24 x 16 regions, margin FOUR (102 + 53 KB; margin 5 fits only a 640-thread workgroup), 960 threads; patch
             //                kernel 314 / 292 / 299 us at sigma 1 / 2 / 3 px, this one 195 / 204 / 241
-            auto launch_window = [&](auto kern, size_t wlds, int threads, int region_px) -> int {
+            // kern_tail: the same configuration with the tail split compiled in (TUNE + 102400; null: this configuration has none)
+            auto launch_window = [&](auto kern, decltype(kern) kern_tail, size_t wlds, int threads, int region_px) -> int {
+                // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
+                // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
+                const int wbound = ((S * 3 / 4 + region_px - 1) / region_px) * 9 / 8 + 2 * L;
+                // + one helper workgroup per CU for the tail split (msda_rw.h: the units of the last, partly filled wave of workgroups are
+                // cut into parts; one workgroup per CU is what the kernel's LDS allows).  SEMIDETR_RW_TAIL=0 builds do without.
+                // Only launches of fewer than ~three waves of workgroups get them (the kernel's own rule, from the real region count): on a
+                // bs-4 launch 256 idle helpers, each waiting for a whole CU to read the level table and leave, cost 7 us of 154.
+                const int cus = (SEMIDETR_RW_TAIL && kern_tail != nullptr) ? device_cus() : 0;
+                const int tail = (int64_t)N * M * ((S * 3 / 4 + region_px - 1) / region_px) < (int64_t)3 * cus ? cus : 0;
+                if (tail > 0) kern = kern_tail;
                 if (int rc = allow_big_lds(kern, wlds, "msda_forward")) {      // refused for this instantiation: the patch kernel below
                     fell_back = true;
                     return rc;
                 }
-                // grid sizing hint: the finest level of a DETR pyramid holds ~3/4 of the pixels; a workgroup takes regions slot,
-                // slot + bound, ... so any bound >= 1 is correct (the level table lives in device memory)
-                const int wbound = ((S * 3 / 4 + region_px - 1) / region_px) * 9 / 8 + 2 * L;
-                SEMIDETR_REQUIRE((int64_t)N * wbound * M < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
-                hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(threads), wlds, st, (const float *)nullptr,
-                                   value, spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs);
+                SEMIDETR_REQUIRE((int64_t)N * wbound * M + tail < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_forward: grid too large");
+                hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M + tail)), dim3(threads), wlds, st, (const float *)nullptr,
+                                   value, spatial_shapes, level_start, io, S, M, wbound, out, (float4 *)nullptr, (int64_t)0, fs, tail);
                 g_last_kernels = "msda_rw_d32";
                 return semidetr::launch_status("msda_rw_d32<forward>");
             };
             auto pick_window = [&]() -> int {
-                constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, SEMIDETR_RW_TUNE>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, SEMIDETR_RW_TUNE5>();
+                constexpr int kTune5 = std::is_same<IO, RawIO>::value ? SEMIDETR_RW_TUNE5_RAW : SEMIDETR_RW_TUNE5;
+                constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, SEMIDETR_RW_TUNE>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, kTune5>();
                 static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
                 if constexpr (std::is_same<IO, RawIO>::value) {
                     if (io.has_mask()) {
@@ -627,16 +659,19 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
                             constexpr size_t wlds4m = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, SEMIDETR_RW_TUNE_MASK>();
                             static_assert(wlds4m <= 160 * 1024, "region-window configuration does not fit the LDS");
                             return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE_MASK, true>,
+                                                 &msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE_MASK + 102400, true>,
                                                  wlds4m, SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
                         }
-                        return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5, true>, wlds5,
+                        constexpr size_t wlds5m = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, SEMIDETR_RW_TUNE5_MASK>();
+                        return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5_MASK, true>, nullptr, wlds5m,
                                              SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5 * 16);
                     }
                 }
                 if (L == 4)
-                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE>, wlds4,
+                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE>,
+                                         &msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE + 102400>, wlds4,
                                          SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
-                return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, SEMIDETR_RW_TUNE5>, wlds5, SEMIDETR_RW_NT5,
+                return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, kTune5>, nullptr, wlds5, SEMIDETR_RW_NT5,
                                      SEMIDETR_RW_RTH5 * 16);
             };
             const int wrc = pick_window();

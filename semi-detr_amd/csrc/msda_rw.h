@@ -72,9 +72,15 @@ struct RwWin {
     static constexpr int total = zrow + zrows;
 };
 
-template <int KL, bool FG = false, bool PRE = false>
+template <int KL, bool FG = false, bool PRE = false, bool WIDE = false>
 constexpr int rw_oct_bytes()      // per octet: {float4 record} and {two 16-bit window offsets} per windowed sample | two 32-byte slots (+ bank spread)
 {
+    // WIDE (TUNE + 51200, forward with level 0 through global loads): the two window offsets of a sample as two 32-bit BYTE offsets --
+    // the loop adds the lane's base to each (2 VALU per sample instead of shift / mask / add / bit-field extract / shift-add)
+    if (WIDE) {
+        constexpr int raww = (KL - 1) * kPT * 24 + kPT * 32;
+        return raww + (raww % 128 == 0 ? 16 : 0);
+    }
     // level 0 without a window (FG): its samples have no window record; their {corner offsets, weights} records (32 bytes each) are
     // dead by the time the out-of-window loop needs its two slots, so the slots lie on top of them -- unless out-of-window samples
     // are pre-issued (PRE: TUNE % 10 > 0), whose slots are written while those records are still live
@@ -92,7 +98,7 @@ constexpr int kRwQList = 1024;      // TUNE + 12800: slots of the region's query
 template <int NT, int RTH, int RTW, int H0, int HC, int KL, int TUNE = 0>
 constexpr size_t rw_lds_bytes()
 {
-    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)(NT / 8) * rw_oct_bytes<KL, (H0 < 0), (TUNE % 10 > 0)>() +
+    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)(NT / 8) * rw_oct_bytes<KL, (H0 < 0), (TUNE % 10 > 0), (((TUNE / 100) & 512) != 0)>() +
            (((TUNE / 100) & 64) ? (size_t)(KL + 1) * 48 : 0) + (((TUNE / 100) & 128) ? (size_t)kRwQList * 4 : 0);
 }
 
@@ -161,6 +167,9 @@ __device__ __forceinline__ void rw_fma4(float4 &acc, const float4 &w, const floa
 //             loop adds 0 x finite), and the out-of-window loop builds the four corner offsets from that and the level table on all
 //             eight lanes -- instead of the owner lane redoing the whole geometry from (x, y) inside a branch (publish), a slot write,
 //             a wait and a slot read per sample.  The sampling data (x, y, attention of both passes) die before the LDS loop.
+//        512  (forward, level 0 through global loads) a sample's two window offsets as two 32-bit byte offsets: 8 instead of 4 bytes
+//             per record, 2 instead of 5 VALU instructions per sample of the LDS loop, no packing in the geometry
+//       1024  the tail split of small launches (helper workgroups take part of the rounds of the last wave's units, see the kernel)
 //        128  the region's query list (slot -> query) is worked out once per region into LDS; a round reads its slot instead of
 //             redoing the level search, five shuffles and a division (~35 instructions and 7 ds_bpermute per round)
 //        Product: 1920 = 16 + 2 + 1, two samples per barrier (four levels); 1110 = 8 + 2 + 1, one sample per barrier (five levels).
@@ -168,15 +177,17 @@ template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GA
 __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(      // 256-thread workgroups: two per CU
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int regions_bound, float *__restrict__ out,
-    float4 *__restrict__ zero, int64_t zero_n4, const FwdStats fs = FwdStats{nullptr, nullptr, nullptr, nullptr})
+    float4 *__restrict__ zero, int64_t zero_n4, const FwdStats fs = FwdStats{nullptr, nullptr, nullptr, nullptr}, int tail_cus = 0)
 {
     io.same_dims(S, M, KL);
     using Wn = RwWin<RTH, RTW, H0, HC, KL>;
     constexpr int P = kPT, KLP = KL * P, G = NT / 8, NPASS = (KLP + 7) / 8;
     constexpr bool FG = Wn::fine_global;                  // level 0 through global loads (forward only)
-    constexpr int kOctBytes = rw_oct_bytes<KL, FG, (TUNE % 10 > 0)>();
+    constexpr bool kWide = ((TUNE / 100) & 512) != 0;
+    static_assert(!kWide || (FG && !GATHER && TUNE % 10 == 0), "wide window offsets: the forward's product shape");
+    constexpr int kOctBytes = rw_oct_bytes<KL, FG, (TUNE % 10 > 0), kWide>();
     constexpr int kRec0 = FG ? P : 0;                     // first sample with a window record
-    constexpr int kOffAt = (KLP - kRec0) * 16, kFineAt = (KLP - kRec0) * 20, kSlotAt = (FG && TUNE % 10 > 0) ? kFineAt + P * 32 : kFineAt;
+    constexpr int kOffAt = (KLP - kRec0) * 16, kFineAt = (KLP - kRec0) * (kWide ? 24 : 20), kSlotAt = (FG && TUNE % 10 > 0) ? kFineAt + P * 32 : kFineAt;
     static_assert(Wn::total * 128 <= (1 << 20), "window offsets are kept in 16 bits, in units of 16 bytes");
     constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
     static_assert(P == 4 && KLP <= 32, "lane j of an octet owns samples j, j + 8, ...");
@@ -208,12 +219,6 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             tmark = now;
         }
     };
-    const int m = (b % M + (b / M) / kRwHeadRun) % M;
-    const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
-    // how far the samples reach, for the dispatcher's choice between this kernel and the patch kernel (FwdStats, msda_fast.h):
-    // one workgroup in 128 counts (its first round: G = NT / 8 queries x 12 samples; ~20 workgroups of a bs-4 launch), the launch's first
-    // workgroup publishes the previous launch's pair
-    const bool sampled = !GATHER && fs.cur != nullptr && (b & 127) == 1;
     unsigned st_far = 0, st_total = 0;
 
     if (GATHER && zero) {      // side job: clear grad_value, which the scatter launch that FOLLOWS accumulates into
@@ -243,6 +248,44 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     // for this one)
     const int Hb = Hs[0], Wb = Ws[0];
     const int nry = (Hb + RTH - 1) / RTH, nrx = (Wb + RTW - 1) / RTW;
+
+    // ---- which (image, head, region) is mine -- and the TAIL SPLIT (round 5).  One workgroup per CU, every (image, head, region) unit
+    // about equally long: a launch of U units takes ceil(U / CUs) unit times -- 1408 units on 256 CUs = 6 for 5.5 (bs 4), 352 = 2 for
+    // 1.4 (bs 1).  So the units of the last, partly filled wave (in dispatch order: the last U mod CUs ones) are cut into s =
+    // CUs / (U mod CUs) parts of their ROUNDS (rounds are independent); part 0 stays with the unit's own workgroup, the others go to
+    // `tail_cus` helper workgroups appended to the grid (dispatched last; the ones not needed leave at once).  Each part stages the
+    // region's windows again (8 % of a unit), so the last wave takes ~0.6 instead of 1 unit time.  tail_cus = 0: no helpers.
+    // Small launches only, see s_ below.
+    // It is its own instantiation (TUNE + 102400), launched for small launches only: with the code merely PRESENT the four-image launch
+    // measured 1.7 % slower inside the step (different schedule of the same loop), which is more than the one-image launch gains.
+    constexpr bool kTail = !GATHER && ((TUNE / 100) & 1024) != 0;
+    int b_unit = b, part = 0, nparts = 1;
+    if (kTail && tail_cus > 0) {
+        const int nreg_all = nry * nrx, base_grid = (int)gridDim.x - tail_cus;
+        const int nimg = base_grid / (regions_bound * M);
+        const int U = nimg * nreg_all * M, full = U / tail_cus * tail_cus, rem = U - full;
+        // (a workgroup takes one region only while the grid's bound covers the region grid; otherwise no split)
+        // ... and only launches of fewer than three waves are cut: measured (tools/r05_ab_fwd.sh) one image 56.8 -> 50.8 us, but four
+        // images (5.5 waves, unit times spread by the narrow edge regions, the tail filled anyway) 175.3 -> 178.6 us
+        const int s_ = (rem > 0 && regions_bound >= nreg_all && U < 3 * tail_cus) ? min(tail_cus / rem, 4) : 1;
+        if (b >= base_grid) {
+            const int hidx = b - base_grid;
+            if (s_ <= 1 || hidx >= rem * (s_ - 1)) return;      // (the whole workgroup, before any barrier)
+            const int u = full + hidx % rem;
+            part = 1 + hidx / rem;
+            nparts = s_;
+            b_unit = ((u / (nreg_all * M)) * regions_bound + (u / M) % nreg_all) * M + u % M;
+        } else {
+            const int sl = (b / M) % regions_bound, ni = (b / M) / regions_bound;
+            if (s_ > 1 && sl < nreg_all && (ni * nreg_all + sl) * M + b % M >= full) nparts = s_;
+        }
+    }
+    const int m = (b_unit % M + (b_unit / M) / kRwHeadRun) % M;
+    const int slot0 = (b_unit / M) % regions_bound, n = (b_unit / M) / regions_bound;
+    // how far the samples reach, for the dispatcher's choice between this kernel and the patch kernel (FwdStats, msda_fast.h):
+    // one workgroup in 128 counts (its first round: G = NT / 8 queries x 12 samples; ~20 workgroups of a bs-4 launch), the launch's first
+    // workgroup publishes the previous launch's pair
+    const bool sampled = !GATHER && fs.cur != nullptr && (b & 127) == 1 && part == 0;
 
     const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)n * S * M * kD, (unsigned)S * M * kD * 4u);
     const unsigned lane_b = (unsigned)(m * kD + 4 * j8) * 4u;
@@ -391,7 +434,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         };
 
         // ---- rounds: G queries at a time, 8 lanes each
-        const int nrounds = (nq_total + G - 1) / G;
+        const int nrounds_all = (nq_total + G - 1) / G;
+        const int round0 = part * nrounds_all / nparts, nrounds = (part + 1) * nrounds_all / nparts;      // my share of the rounds (all of them unless the unit is split)
         auto slot_query = [&](int s) -> int {      // s-th query of the region (levels in order) or -1
             const bool ok = s < nq_total;
             int lq = 0;
@@ -411,7 +455,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         typename IO::RawXY rr[NPASS];
         float rx[NPASS], ry[NPASS], ra[NPASS];
         float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-        int q = slot_query(lane_t >> 3);
+        int q = slot_query(round0 * G + (lane_t >> 3));
         auto load_round = [&](int qq, int j8) {      // (j8: the caller's copy -- the lean builds rebuild it per round)
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
@@ -518,7 +562,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
         __syncthreads();                   // the windows are complete
         lap(4);                            // 4: waiting for the other waves' stores
 
-        for (int round = 0; round < nrounds; ++round) {
+        for (int round = round0; round < nrounds; ++round) {
             // queries are dealt out in order, so a wave without one in this round has none in the later ones either: it leaves the
             // loop (no workgroup barrier inside) instead of spending issue slots on empty octets -- a region's 340 queries fill
             // 3.5 rounds of 96
@@ -668,7 +712,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                             inside ? make_float4(lw, lh, a, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 if (k < KLP && !(FG && k < P)) {
-                    *reinterpret_cast<unsigned *>(orec + kOffAt + (k - kRec0) * 4) = (first >> 4) | ((partner >> 4) << 16);
+                    if constexpr (kWide) *reinterpret_cast<uint2 *>(orec + kOffAt + (k - kRec0) * 8) = make_uint2(first, partner);
+                    else *reinterpret_cast<unsigned *>(orec + kOffAt + (k - kRec0) * 4) = (first >> 4) | ((partner >> 4) << 16);
                     if (!GATHER) {
                         const float wl_t = inwin ? a * (hh * hw) : 0.f, wl_b = inwin ? a * (lh * hw) : 0.f;
                         const float wr_t = inwin ? a * (hh * lw) : 0.f, wr_b = inwin ? a * (lh * lw) : 0.f;
@@ -882,9 +927,13 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 for (int k = FG ? P : 0; k < KLP; ++k) {
                     const int pitch = Wn::ww(k / P) * 128;
                     const float4 r = *reinterpret_cast<const float4 *>(orec + (k - kRec0) * 16);
-                    const unsigned o = *reinterpret_cast<const unsigned *>(orec + kOffAt + (k - kRec0) * 4);
+                    const unsigned o = kWide ? 0u : *reinterpret_cast<const unsigned *>(orec + kOffAt + (k - kRec0) * 4);
                     const char *a0, *a1;
-                    if constexpr (((TUNE / 100) & 32) != 0) {
+                    if constexpr (kWide) {
+                        const uint2 ow = *reinterpret_cast<const uint2 *>(orec + kOffAt + (k - kRec0) * 8);
+                        a0 = wbase + ow.x;
+                        a1 = wbase + ow.y;
+                    } else if constexpr (((TUNE / 100) & 32) != 0) {
                         // TUNE + 3200: window address = base + 16 x (16-bit offset) as ONE v_mad_u32_u16 each (op_sel picks the half of
                         // the packed word) instead of shift / mask / add: 2 instead of 5 VALU instructions per sample
                         unsigned u0, u1;
