@@ -481,8 +481,11 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 // 243 / 251 / 261 / 283 us against the patch kernel's 270-273 us at sigma 3.5 / 4 / 4.5 / 5 / 6 px -- level at ~5.5 px = a far share of
 // ~0.71; five levels level at ~5 px = ~0.67.  One image alone (616 regions x heads for 256 CUs) used to need its own, lower bound;
 // the larger workgroups removed the difference (57 / 63 / 65.5 / 68.5 against 68 / 70.5 / 71.5 / 72 us at 2 / 3 / 3.5 / 4 px).
-constexpr float kFarToWindow = 0.60f;      // patch -> window when fewer than this share of the samples are far ...
-constexpr float kFarToPatch = 0.70f;       // ... window -> patch above this one
+// Round 5 (the window kernel's geometry halved, tools/r05_crossover.sh): four levels, bs 4: 193 / 213 / 232 / 246 / 255 / 260 us against the patch
+// kernel's 263-270 at sigma 3 / 4 / 5 / 6 / 7 / 8 px -- level beyond 8 px (far share 0.85); one image: 56 / 63 / 68 / 70.5 / 74.5 against 70-71 --
+// level at ~6 px (0.76).  The band moves from 0.60 / 0.70 to 0.72 / 0.80.
+constexpr float kFarToWindow = 0.72f;      // patch -> window when fewer than this share of the samples are far ...
+constexpr float kFarToPatch = 0.80f;       // ... window -> patch above this one
 constexpr float kFarToWindow5 = 0.56f, kFarToPatch5 = 0.66f;      // five levels (COCO-Full pyramid: margin 4 instead of 6)
 // Per CALL SITE (round 5): the reference builds twelve MSDeformAttn instances per model (transformer.py:609,760) whose learned offsets
 // reach differently far, so the state is kept per (device, slot): the caller names the slot in bits 8..15 of `flags`

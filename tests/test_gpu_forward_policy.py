@@ -237,7 +237,7 @@ def test_window_forward_full_size_mixed_image_shapes_vs_oracle(levels):
 
 
 def test_adaptive_policy_follows_the_sample_spread():
-    """Close samples (sigma 1 px) -> the dispatcher moves to the window kernel; far samples (sigma 7 px) -> back to the patch
+    """Close samples (sigma 1 px) -> the dispatcher moves to the window kernel; far samples (sigma 14 px) -> back to the patch
     kernel; results equal the oracle's throughout.  (The count of launch k reaches the host when launch k + 1 starts and is
     acted on by the dispatch after that, so a few launches with a synchronisation in between are needed: in training the
     host runs ahead and the choice simply lags by a step.)"""
@@ -266,16 +266,16 @@ def test_adaptive_policy_follows_the_sample_spread():
     k_close = run(1.0, 6)
     st1 = sda._lib.forward_policy_state()
     assert st1["updates"] > st0["updates"], (st0, st1)
-    assert st1["mode"] == 1 and 0.0 <= st1["far_fraction"] < 0.60, st1
+    assert st1["mode"] == 1 and 0.0 <= st1["far_fraction"] < 0.72, st1
     assert k_close[-1] == "msda_rw_d32", k_close
-    k_far = run(7.0, 6)
+    k_far = run(14.0, 6)
     st2 = sda._lib.forward_policy_state()
-    assert st2["mode"] == 0 and st2["far_fraction"] > 0.70, st2
+    assert st2["mode"] == 0 and st2["far_fraction"] > 0.80, st2
     assert k_far[0] == "msda_rw_d32" and k_far[-1] == "msda_fwd_d32<1, 4, 408", k_far
 
 
 def test_adaptive_policy_is_kept_per_call_site():
-    """Two "layers" whose offsets reach differently far (sigma 1 px and 7 px), called alternately as the layers of an encoder are
+    """Two "layers" whose offsets reach differently far (sigma 1 px and 14 px), called alternately as the layers of an encoder are
     (the reference builds twelve MSDeformAttn instances per model, transformer.py:609,760): with a slot each
     (SEMIDETR_MSDA_POLICY_SLOT, the module's `policy_slot`) each settles on ITS kernel and stays there, whatever the other one
     does; the shared slot 0 is not touched.  Results equal the oracle's throughout."""
@@ -287,7 +287,7 @@ def test_adaptive_policy_is_kept_per_call_site():
     tsh = _t(shp)
     tls = _starts(tsh)
     layers = {}
-    for slot, sigma in ((7, 1.0), (8, 7.0)):
+    for slot, sigma in ((7, 1.0), (8, 14.0)):
         value, _, ref, off, logits, _ = _encoder_case(2, shapes, sigma, 40 + slot)
         loc, attn = _prologue_np(ref, off, logits, shp, P)
         layers[slot] = ((_t(value), tsh, tls, _t(loc), _t(attn), 64, slot), oracle.msda_forward(value, shp, loc, attn))
@@ -300,8 +300,8 @@ def test_adaptive_policy_is_kept_per_call_site():
             torch.cuda.synchronize()
             np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6)
     st7, st8 = sda._lib.forward_policy_state(7), sda._lib.forward_policy_state(8)
-    assert st7["mode"] == 1 and st7["far_fraction"] < 0.60 and st7["updates"] >= 5, st7
-    assert st8["mode"] == 0 and st8["far_fraction"] > 0.70 and st8["updates"] >= 5, st8
+    assert st7["mode"] == 1 and st7["far_fraction"] < 0.72 and st7["updates"] >= 5, st7
+    assert st8["mode"] == 0 and st8["far_fraction"] > 0.80 and st8["updates"] >= 5, st8
     assert set(seen[7][4:]) == {"msda_rw_d32"}, seen[7]                 # settled after a few launches, then never moved
     assert set(seen[8]) == {"msda_fwd_d32<1, 4, 408"}, seen[8]
     assert sda._lib.forward_policy_state(0)["updates"] == before0
