@@ -1103,8 +1103,9 @@ def main():
                        "pmc_source": ("profiles/" + TA_JSON) if ta_ev else None,
                        "note": ("region-window kernel: level-0 corner rows (1 / L of the 4 x 128 B per sample; far samples of the coarse "
                                 "levels not counted) through the vector-memory return vs 256 CU x 64 B/clk x 2400 MHz, the coarse levels' "
-                                "corner rows from LDS (`lds_return`) vs 256 CU x 256 B/clk x 2400 MHz -- neither pipe is the limit, "
-                                "the kernel is a chain of dependent phases per round at three waves per SIMD (DESIGN.md 2.1b)"
+                                "corner rows from LDS (`lds_return`) vs 256 CU x 256 B/clk x 2400 MHz -- neither pipe is the limit: "
+                                "timing aids (round 5) put 45 % of the kernel into geometry / records / address arithmetic, i.e. VALU and "
+                                "scalar instruction issue at three waves per SIMD (DESIGN.md 2.1b, 'an INSTRUCTION problem')"
                                 if window_fwd else
                                 "patch kernel: corner rows (4 x 128 B per sample) / launch time vs 256 CU x 64 B/clk x 2400 MHz; this "
                                 "vector-memory INSTRUCTION path (16 cycles per 64-lane buffer_load_dwordx4) is what binds it "
