@@ -618,7 +618,9 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
         // own instantiation: padded rows are staged as zeros, level 0 drops padded corners from its records (msda_rw.h).
         // SEMIDETR_MSDA_FIXED_FORWARD: the caller wants the kernel to be a function of the arguments alone (bitwise reproducible
         // forward: the two kernels sum in different orders) -- the patch kernel, whatever the policy says.
-        const bool window_ok = P == kPT && (L == 4 || L == 5) && !(flags & SEMIDETR_MSDA_FIXED_FORWARD);
+        // (an image's sampling data and output below 2^32 bytes: the window kernel indexes them with 32 bits inside the image)
+        const bool window_ok = P == kPT && (L == 4 || L == 5) && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) &&
+                               (uint64_t)S * M * L * P * 8 < (1ull << 32) && (uint64_t)S * M * kD * 4 < (1ull << 32);
         FwdStats fs;
         bool use_window = false;
         if (int rc = fwd_adapt_next(st, window_ok, (flags >> 8) & 0xff, L, fs, use_window)) return rc;
@@ -733,7 +735,9 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         float4 *zero = fill_in_gather ? reinterpret_cast<float4 *>(grad_value) : nullptr;
         bool window_gather = false;
         // (SEMIDETR_MSDA_FIXED_FORWARD: which gather runs must not depend on earlier launches either -- the patch gather)
-        if (L == 4 && P == kPT && fill_in_gather && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff)) {
+        // (Lq * M * L * P * 8 bytes per image < 2^32: msda_gw_d32 indexes the sampling data inside an image with 32 bits)
+        if (L == 4 && P == kPT && fill_in_gather && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff) &&
+            (uint64_t)Lq * M * L * P * 8 < (1ull << 32)) {
             // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
             auto launch_gw = [&](auto kern) -> bool {
                 constexpr size_t wl = gw_lds_bytes<SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();

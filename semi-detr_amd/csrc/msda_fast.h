@@ -64,11 +64,20 @@ struct LocAttnIO {
     const float *loc, *attn;
     float *gloc, *gattn;
     static constexpr bool kSoftmax = false;      // attn already holds probabilities
+    // The accessors take the row index (image, query, head) and the (image, query) index in the caller's integer type: int64_t over the
+    // whole batch, or -- on the view of ONE image (pointers advanced, wave-uniform) -- unsigned indices inside the image, whose address
+    // arithmetic is 32-bit (the 64-bit multiplies are ~40 half-rate VALU instructions per round of the lane-per-sample gather).
+    __device__ __forceinline__ LocAttnIO image_view(int n, int Lq, int M_, int LP) const
+    {
+        const int64_t o = (int64_t)n * Lq * M_ * LP;
+        return LocAttnIO{loc + o * 2, attn + o, gloc ? gloc + o * 2 : nullptr, gattn ? gattn + o : nullptr};
+    }
     __device__ __forceinline__ bool masked(int n, int pixel) const { (void)n; (void)pixel; return false; }
     __host__ __device__ __forceinline__ bool has_mask() const { return false; }
     __device__ __forceinline__ MaskExt mask_ext(int n, int l) const { (void)n; (void)l; return MaskExt{-1}; }
     __device__ __forceinline__ void same_dims(int S_, int M_, int L_) const { (void)S_; (void)M_; (void)L_; }
-    __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+    template <typename R>
+    __device__ __forceinline__ void load_xy(R row, R nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
         (void)nq; (void)l; (void)P; (void)H; (void)W;
@@ -78,7 +87,8 @@ struct LocAttnIO {
     }
     // two-step form for callers that load a round ahead: what the loads return, and the arithmetic that turns it into (x, y)
     struct RawXY { float2 xy; };
-    __device__ __forceinline__ RawXY load_xy_raw(int64_t row, int64_t nq, int LP, int k, int l) const
+    template <typename R>
+    __device__ __forceinline__ RawXY load_xy_raw(R row, R nq, int LP, int k, int l) const
     {
         (void)nq; (void)l;
         return RawXY{ld_stream2(loc + (row * LP + k) * 2)};
@@ -89,9 +99,11 @@ struct LocAttnIO {
         x = r.xy.x;
         y = r.xy.y;
     }
-    __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return ld_stream1(attn + row * LP + k); }
+    template <typename R>
+    __device__ __forceinline__ float load_w(R row, int LP, int k) const { return ld_stream1(attn + row * LP + k); }
     // res = {d/d attn, d/d loc.x, d/d loc.y, attn} of sample k; row_res = the LP results of the same (n,q,m) row
-    __device__ __forceinline__ void store(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+    template <typename R>
+    __device__ __forceinline__ void store(R row, R nq, int LP, int k, int l, int P, int H, int W,
                                           const float4 res, const float4 *row_res) const
     {
         (void)nq; (void)l; (void)P; (void)H; (void)W; (void)row_res;
@@ -99,7 +111,8 @@ struct LocAttnIO {
         st_stream2(gloc + (row * LP + k) * 2, make_float2(res.y, res.z));
     }
     // same, for callers that hold the row's sum_j a_j g_j already (unused here)
-    __device__ __forceinline__ void store_with_dot(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+    template <typename R>
+    __device__ __forceinline__ void store_with_dot(R row, R nq, int LP, int k, int l, int P, int H, int W,
                                                    const float4 res, float dot) const
     {
         (void)dot;
@@ -137,6 +150,19 @@ struct RawIO {
     unsigned ref_bytes;                          // size of `ref` (N * Lq * L * ref_dim floats): bound of its buffer resource
     const int *mext;                             // (N, L) words per (image, level), see MaskExt; null: none (every corner reads its byte)
     static constexpr bool kSoftmax = true;       // load_w returns a raw logit; the kernel normalises the row
+    // view of ONE image for 32-bit index arithmetic (see LocAttnIO::image_view); the mask and its summaries keep their image index
+    __device__ __forceinline__ RawIO image_view(int n, int Lq, int M_, int LP) const
+    {
+        RawIO r = *this;
+        const int64_t o = (int64_t)n * Lq * M_ * LP, ro = (int64_t)n * Lq * L * ref_dim;
+        r.ref = ref + ro;
+        r.off = off + o * 2;
+        r.logit = logit + o;
+        r.goff = goff ? goff + o * 2 : nullptr;
+        r.glogit = glogit ? glogit + o : nullptr;
+        r.ref_bytes = (unsigned)Lq * L * ref_dim * 4u;
+        return r;
+    }
     __device__ __forceinline__ bool masked(int n, int pixel) const { return mask[(int64_t)n * S + pixel] != 0; }
     __host__ __device__ __forceinline__ bool has_mask() const { return mask != nullptr; }
     // The kernels get S / M / L as arguments of their own: telling the compiler that the copies in here are the same numbers lets it
@@ -153,7 +179,8 @@ struct RawIO {
         if (!mask || !mext) return MaskExt{-1};
         return MaskExt{mext[n * L + l]};
     }
-    __device__ __forceinline__ void load_xy(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+    template <typename R>
+    __device__ __forceinline__ void load_xy(R row, R nq, int LP, int k, int l, int P, int H, int W,
                                             float &x, float &y) const
     {
         // BRANCH-FREE on purpose.  With `if (ref_dim == 2) ... else ...` around the loads every call became its own
@@ -167,7 +194,8 @@ struct RawIO {
         finish_xy(o, r, P, H, W, x, y);
     }
     struct RawXY { float2 o; float4 r; };      // offset and reference point as loaded (see LocAttnIO::RawXY)
-    __device__ __forceinline__ RawXY load_xy_raw(int64_t row, int64_t nq, int LP, int k, int l) const
+    template <typename R>
+    __device__ __forceinline__ RawXY load_xy_raw(R row, R nq, int LP, int k, int l) const
     {
         return RawXY{ld_stream2(off + (row * LP + k) * 2), buf_ld4(image_rsrc(ref, ref_bytes), (unsigned)((nq * L + l) * ref_dim) * 4u)};
     }
@@ -185,9 +213,11 @@ struct RawIO {
         x = r.x + o.x * sx;
         y = r.y + o.y * sy;
     }
-    __device__ __forceinline__ float load_w(int64_t row, int LP, int k) const { return ld_stream1(logit + row * LP + k); }
+    template <typename R>
+    __device__ __forceinline__ float load_w(R row, int LP, int k) const { return ld_stream1(logit + row * LP + k); }
     // called by the LP consecutive threads that own the row's samples (see row_softmax)
-    __device__ __forceinline__ void store(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+    template <typename R>
+    __device__ __forceinline__ void store(R row, R nq, int LP, int k, int l, int P, int H, int W,
                                           const float4 res, const float4 *row_res) const
     {
         float dot = res.w * res.x;               // softmax backward: a_k * (g_k - sum_j a_j g_j)
@@ -200,7 +230,8 @@ struct RawIO {
         store_with_dot(row, nq, LP, k, l, P, H, W, res, dot);
     }
     // dot = sum_j a_j g_j over the row (softmax backward), supplied by the caller
-    __device__ __forceinline__ void store_with_dot(int64_t row, int64_t nq, int LP, int k, int l, int P, int H, int W,
+    template <typename R>
+    __device__ __forceinline__ void store_with_dot(R row, R nq, int LP, int k, int l, int P, int H, int W,
                                                    const float4 res, float dot) const
     {
         st_stream1(glogit + row * LP + k, res.w * (res.x - dot));
@@ -358,8 +389,8 @@ __device__ __forceinline__ float lp_group_max(float x, int LP)
     return x;
 }
 
-template <typename IO>
-__device__ __forceinline__ float row_softmax(const IO &io, int64_t row, int LP, int k, float raw)
+template <typename IO, typename R>
+__device__ __forceinline__ float row_softmax(const IO &io, R row, int LP, int k, float raw)
 {
     if (!IO::kSoftmax) return raw;
     if (lp_shuffles(LP)) {

@@ -251,12 +251,15 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             typename IO::RawXY rxy;
             float raw;
         };
+        // (the sampling data and the results are addressed inside MY image: 32-bit index arithmetic on the image's view of the tensors --
+        //  the launcher checks Lq * M * L * P * 8 < 2^32 -- instead of 64-bit multiplies by every lane in every round)
+        const IO ion = io.image_view(n, Lq, M, LP);
         auto fetch = [&](int round_, Pre &p) {
             p.q = query_of_slot(round_ * QPR + (tid >> 4));
-            const int qs_ = p.q >= 0 ? p.q : 0;       // (a lane without a query reads query 0 of the image and stores nothing)
-            const int64_t nq_ = (int64_t)n * Lq + qs_, row_ = nq_ * M + m;
-            p.rxy = io.load_xy_raw(row_, nq_, LP, k, lvl);
-            p.raw = io.load_w(row_, LP, k);
+            const unsigned qs_ = p.q >= 0 ? (unsigned)p.q : 0u;       // (a lane without a query reads query 0 of the image and stores nothing)
+            const unsigned row_ = qs_ * (unsigned)M + (unsigned)m;
+            p.rxy = ion.load_xy_raw(row_, qs_, LP, k, lvl);
+            p.raw = ion.load_w(row_, LP, k);
         };
         float4 go[8];
         // (my chunk swizzle goes through an empty asm where it is used: the compiler would otherwise keep all its derived offsets --
@@ -280,11 +283,11 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             if (round + 1 < nrounds) fetch(round + 1, nxt);
             const bool act = q >= 0;
             const int qs = act ? q : 0;
-            const int64_t nq = (int64_t)n * Lq + qs, row = nq * M + m;
+            const unsigned nq = (unsigned)qs, row = nq * (unsigned)M + (unsigned)m;      // (inside my image: `ion`)
             float x, y;
             io.finish_xy_raw(cur.rxy, P, myH, myW, x, y);
             const float raw = cur.raw;
-            const float a = row_softmax(io, row, LP, k, raw);      // fused prologue: over the 16 lanes of my DPP row
+            const float a = row_softmax(ion, row, LP, k, raw);      // fused prologue: over the 16 lanes of my DPP row
 
             // ---- geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 zero padding)
             const float Hf = (float)myH, Wf = (float)myW;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             const float g_y = inside ? a * (b_ - t_) : 0.f;
             float dot = 0.f;                       // fused epilogue: sum_k a_k g_k over the row (softmax backward)
             if (IO::kSoftmax) dot = lp_group_sum(a * g_a, 16);
-            if (act) io.store_with_dot(row, nq, LP, k, lvl, P, myH, myW, make_float4(g_a, g_x * Wf, g_y * Hf, a), dot);
+            if (act) ion.store_with_dot(row, nq, LP, k, lvl, P, myH, myW, make_float4(g_a, g_x * Wf, g_y * Hf, a), dot);
         }
     }
 }

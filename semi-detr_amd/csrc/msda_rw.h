@@ -290,6 +290,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)n * S * M * kD, (unsigned)S * M * kD * 4u);
     const unsigned lane_b = (unsigned)(m * kD + 4 * j8) * 4u;
     const unsigned row_bytes = (unsigned)rs * 4u;
+    // forward: the sampling data and `out` are addressed inside MY image (the launcher checks that an image's tensors stay below 2^32
+    // bytes): 32-bit index arithmetic instead of 64-bit multiplies per lane and round
+    constexpr bool kView = !GATHER && kTab;
+    const IO iov = kView ? io.image_view(n, Lq, M, KLP) : io;
+    float *const out_n = kView ? out + (int64_t)n * Lq * M * kD : out;
     // MASK: this image's (S,) padding bytes.  Rebuilt where it is used (the image index goes through an empty asm): as a kernel-long
     // value the pointer was the scalar register pair that pushed another one out to scratch.
     const unsigned char *mask_n = nullptr;
@@ -462,14 +467,15 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 const int k = j8 + 8 * p;
                 rx[p] = ry[p] = ra[p] = 0.f;
                 if (qq >= 0 && k < KLP) {
-                    const int64_t nq = (int64_t)n * Lq + qq, row = nq * M + m;
+                    // (kView: inside my image, 32-bit index arithmetic on the image's view of the tensors)
+                    const typename std::conditional<kView, unsigned, int64_t>::type nq = kView ? (int64_t)qq : (int64_t)n * Lq + qq, row = nq * M + m;
                     if constexpr (kSplitLoad) {
-                        rr[p] = io.load_xy_raw(row, nq, KLP, k, k / P);
+                        rr[p] = iov.load_xy_raw(row, nq, KLP, k, k / P);
                     } else {
                         const LvlC c = lvlc(p);
-                        io.load_xy(row, nq, KLP, k, c.l, P, c.H, c.W, rx[p], ry[p]);
+                        iov.load_xy(row, nq, KLP, k, c.l, P, c.H, c.W, rx[p], ry[p]);
                     }
-                    ra[p] = io.load_w(row, KLP, k);
+                    ra[p] = iov.load_w(row, KLP, k);
                 }
             }
             if (GATHER && qq >= 0)
@@ -1096,7 +1102,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             if (DBG == 1 && tid == 0) SEMIDETR_DBG_ADD(10, 1);
             // ---- results
             if (!GATHER) {
-                if (q_cur >= 0) st_stream4(out + (((int64_t)n * Lq + q_cur) * M + m) * kD + 4 * j8, acc);
+                if (q_cur >= 0) {
+                    if constexpr (kView) st_stream4(out_n + (size_t)((unsigned)(q_cur * M + m) * (unsigned)kD + 4u * (unsigned)j8), acc);
+                    else st_stream4(out + (((int64_t)n * Lq + q_cur) * M + m) * kD + 4 * j8, acc);
+                }
             } else {
                 float dot = 0.f;                   // fused epilogue: sum_k a_k g_k over the row
                 if (IO::kSoftmax) {
