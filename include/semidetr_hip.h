@@ -153,12 +153,12 @@ int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, 
  * produce the same results at different speeds depending on how far the learned offsets reach:
  *   patch kernel   -- 4 x 8 query patches, every corner row through the vector-memory path; insensitive to the offsets
  *   window kernel  -- regions of up to 25 x 16 pixels, the coarse levels' corner rows from LDS windows +- 5 px (five levels: +- 4 px) around
- *                     the region; ~30 % faster while most samples stay inside (sigma <= 2 px), level with the patch kernel when
- *                     ~70 % of them are more than 4 px away (sigma ~5.5 px), slower beyond (profiles/r04_region_window_dispatch.txt)
+ *                     the region; ~35 % faster while most samples stay inside (sigma <= 2 px), level with the patch kernel when
+ *                     ~85 % of them are more than 4 px away (sigma ~8 px at four images, ~6 px for one)
  * policy 0 (default, adaptive): both kernels count, in a few workgroups, the share of samples further than 4 px from their
  *   query's pixel centre; launch k's count reaches the host through mapped pinned memory when launch k + 1 OF THE SAME SLOT starts
  *   (no copy command, no synchronisation) and the NEXT dispatch of that slot moves between the kernels with hysteresis (to the
- *   window kernel below 60 %, back above 70 %; five levels 56 % / 66 %).  State is per (device, slot) -- see
+ *   window kernel below 72 %, back above 80 %; five levels 56 % / 66 %).  State is per (device, slot) -- see
  *   SEMIDETR_MSDA_POLICY_SLOT; launches inside a stream capture keep their slot's kernel of the moment and count nothing.  The
  *   first adaptive dispatch on a device allocates the counters (64 KB of device memory, 4 KB of pinned host memory; the two
  *   allocation calls may synchronise that device once).  Launches of ONE slot on two streams of a device at the same time share
