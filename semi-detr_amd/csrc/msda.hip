@@ -69,7 +69,7 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_GATHER5_KB 4       //  instantiation spills 4 registers there -- left as it is)
 #endif
 #ifndef SEMIDETR_SCATTER_Q       // region scatter: queries per pass (LDS) and waves per SIMD
-#define SEMIDETR_SCATTER_Q 176     // (a region of an 800 x 1333 pyramid has at most 171 queries: one pass; more take several)
+#define SEMIDETR_SCATTER_Q 256     // (an 8 x 24 region of a halving pyramid has 192 + 48 + 12 + 3 queries: one pass; more take several)
 #define SEMIDETR_SCATTER_WPE 6
 #endif
 #ifndef SEMIDETR_SCATTER_WU
@@ -79,10 +79,15 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_SCATTER_NT 512    // (704 threads = one sample per thread, no half-empty second sample slot, two workgroups per CU:
 #endif                             //  encoder backward 726 against 678 us at bs 4 -- the third workgroup is worth more)
 #ifndef SEMIDETR_SCATTER_RTH     // region scatter: region (pixels of the finest level) and window per sampling level
+// Round 5, after the flush path lost its 64-bit arithmetic (the kernel then ran at the atomic unit's rate, compute 328 of 398 us): 8 x 24
+// regions, 24 x 40 windows, 256 queries per pass, 74.5 KB of LDS = TWO workgroups per CU flush 10 % fewer rows -- 400 -> 365 us at bs 4,
+// 118 -> 114 us at bs 1 (tools/r05_ab_kern.sh; 8 x 16 / 176 queries / three per CU was the optimum while compute was the co-limit).
+// Others measured: 12 x 16 390, 10 x 16 385, 8 x 20 387, 8 x 22 383, 8 x 24 with 272 queries (three samples per thread) 375, 576 / 640
+// threads 414 / 406, 16 x 16 at one workgroup per CU 457-514.
 #define SEMIDETR_SCATTER_RTH 8
-#define SEMIDETR_SCATTER_RTW 16
+#define SEMIDETR_SCATTER_RTW 24
 #define SEMIDETR_SCATTER_WH 24
-#define SEMIDETR_SCATTER_WW 32
+#define SEMIDETR_SCATTER_WW 40
 #endif
 #ifndef SEMIDETR_GW_NT           // msda_gw_d32 (lane-per-sample gather of the encoder backward): threads, region, margins of level 0 / the coarse levels
 #define SEMIDETR_GW_NT 768
@@ -788,8 +793,11 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             return semidetr::launch_status("msda_sw_d32");
         }
 #endif
+        // (two workgroups per CU are four waves per SIMD: the fused prologue's instantiation takes that register budget -- at six it
+        //  spills two registers; the reference contract's measured 1.5 % faster with the tighter one)
+        constexpr int kScatterWpe = std::is_same<IO, RawIO>::value ? 4 : SEMIDETR_SCATTER_WPE;
         auto kern = &msda_bwd_scatter_d32_reg<IO, SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, SEMIDETR_SCATTER_RTH, SEMIDETR_SCATTER_RTW,
-                                              SEMIDETR_SCATTER_WH, SEMIDETR_SCATTER_WW, 0, SEMIDETR_SCATTER_WPE, SEMIDETR_SCATTER_WU>;
+                                              SEMIDETR_SCATTER_WH, SEMIDETR_SCATTER_WW, 0, kScatterWpe, SEMIDETR_SCATTER_WU>;
         const size_t rlds = reg_lds_bytes<SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, SEMIDETR_SCATTER_WH, SEMIDETR_SCATTER_WW>();
         if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
         constexpr int kRegPix = SEMIDETR_SCATTER_RTH * SEMIDETR_SCATTER_RTW;
