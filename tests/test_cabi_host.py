@@ -149,6 +149,9 @@ def test_compiled_front_end_is_the_reference_module_surface():
     assert MSDA.pyramid_check(sh, ls, 9) == 0
     sh[1, 1] = 3                                                    # in-place edit bumps the version -> re-evaluated
     assert MSDA.pyramid_check(sh, ls, 8) == 0 and MSDA.pyramid_check(sh, ls, 9) == 3
+    # round 5: the pixel-patch kernels pack a sample's top-left pixel into 15 + 15 bits -- a level side beyond 32766 is not vouched for
+    assert MSDA.pyramid_check(torch.tensor([[1, 32766]]), torch.tensor([0]), 32766) == 3
+    assert MSDA.pyramid_check(torch.tensor([[1, 32767]]), torch.tensor([0]), 32767) == 1
     with pytest.raises(RuntimeError, match="value tensor has to be contiguous|Not implemented on the CPU"):
         MSDA.ms_deform_attn_forward(torch.zeros(1, 4, 2, 2), sh, ls, torch.zeros(1, 1, 2, 2, 1, 2), torch.zeros(1, 1, 2, 2, 1), 64)
 
