@@ -130,7 +130,13 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
     const __amdgpu_buffer_rsrc_t gr = image_rsrc(gout + (int64_t)n * Lq * M * kD, (unsigned)Lq * M * kD * 4u);
     const unsigned row_bytes = (unsigned)rs * 4u, head_b = (unsigned)(m * kD) * 4u;
 
+    const int Hb_k = Hb, Wb_k = Wb, nrx_k = nrx, nry_k = nry;
     for (int reg = slot0; reg < nregions; reg += regions_bound) {
+        // (the region grid's sizes through an empty asm: the reciprocals of the divisions by them are rebuilt per region instead of being
+        //  held -- and at 1024 threads spilled -- for the whole kernel, as in msda_rw_d32)
+        int Hb_r = Hb_k, Wb_r = Wb_k, nrx_r = nrx_k, nry_r = nry_k;
+        asm volatile("" : "+s"(Hb_r), "+s"(Wb_r), "+s"(nrx_r), "+s"(nry_r));
+        const int Hb = Hb_r, Wb = Wb_r, nrx = nrx_r, nry = nry_r;
         // balanced tiling of the region grid (msda_rw_d32): heights / widths differ by at most one, none exceeds RTH / RTW
         const int ry_b = reg / nrx, rx_b = reg - ry_b * nrx;
         const int y0b = (ry_b * Hb) / nry, y1b = ((ry_b + 1) * Hb) / nry;
@@ -333,7 +339,8 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                 e1 = __builtin_elementwise_fma(gh, v2f{f1.z, f1.w}, e1);
                 e2 = __builtin_elementwise_fma(gh, v2f{f2.z, f2.w}, e2);
                 e3 = __builtin_elementwise_fma(gh, v2f{f3.z, f3.w}, e3);
-                if (c & 1) __builtin_amdgcn_sched_barrier(0);      // two steps' reads in flight (the scheduler would hoist all 32: 128 registers)
+                // two steps' reads in flight (the scheduler would hoist all 32: 128 registers); ONE at 1024 threads (128 registers in all)
+                if ((c & 1) || NT >= 1024) __builtin_amdgcn_sched_barrier(0);
             }
             }
             // The next round's grad_out rows go into the registers the loop has just released.  ONE empty asm takes the eight partial
