@@ -91,7 +91,7 @@ constexpr int kMaxLevels = 32;
 #endif
 #ifndef SEMIDETR_GW_NT           // msda_gw_d32 (lane-per-sample gather of the encoder backward): threads, region, margins of level 0 / the coarse levels
 #define SEMIDETR_GW_NT 768
-#define SEMIDETR_GW_NT_LOCATTN 1024
+#define SEMIDETR_GW_NT_WIDE 1024   // ... without a padding mask
 #define SEMIDETR_GW_RTH 16
 #define SEMIDETR_GW_RTW 16
 #define SEMIDETR_GW_H0 4
@@ -745,10 +745,11 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         if (L == 4 && P == kPT && fill_in_gather && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff) &&
             (uint64_t)Lq * M * L * P * 8 < (1ull << 32)) {
             // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
-            // (1024 threads for the reference contract -- 126 VGPRs, round 5: 232 -> 217 us in the probe; the fused prologue's
-            //  instantiations spill 8-12 registers there and stay at SEMIDETR_GW_NT)
-            constexpr int kGwNT = std::is_same<IO, RawIO>::value ? SEMIDETR_GW_NT : SEMIDETR_GW_NT_LOCATTN;
-            auto launch_gw = [&](auto kern) -> bool {
+            // (round 5: 1024 threads = 16 waves per CU for the reference contract and the fused prologue without a mask -- 124 / 128 VGPRs
+            //  once the region grid's division reciprocals and the float copies of the level sizes are rebuilt per region: 232 -> 217 us
+            //  in the probe; the masked instantiation spills the thread index there and stays at SEMIDETR_GW_NT)
+            auto launch_gw = [&](auto kern, auto nt_c) -> bool {
+                constexpr int kGwNT = decltype(nt_c)::value;
                 constexpr size_t wl = gw_lds_bytes<kGwNT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();
                 if (allow_big_lds(kern, wl, "msda_backward") != SEMIDETR_OK) {      // refused: the patch gather below
                     (void)hipGetLastError();
@@ -762,10 +763,12 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             };
             if constexpr (std::is_same<IO, RawIO>::value) {
                 if (io.has_mask())
-                    window_gather = launch_gw(&msda_gw_d32<IO, kGwNT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, true, SEMIDETR_GW_DBG>);
+                    window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, true, SEMIDETR_GW_DBG>,
+                                              std::integral_constant<int, SEMIDETR_GW_NT>());
             }
             if (!window_gather && !io.has_mask())
-                window_gather = launch_gw(&msda_gw_d32<IO, kGwNT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false, SEMIDETR_GW_DBG>);
+                window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT_WIDE, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false, SEMIDETR_GW_DBG>,
+                                          std::integral_constant<int, SEMIDETR_GW_NT_WIDE>());
         }
         if (window_gather) {
         } else if (L * P == 16)             // DINO: sample loop unrolled, results in registers

@@ -145,8 +145,10 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
         int r_ylo = 0, r_xlo = 0, r_w = 1, r_cnt = 0;
         float r_invw = 1.f;
         const float pcy = 0.5f * (float)(y0b + y1b) / (float)Hb, pcx = 0.5f * (float)(x0b + x1b) / (float)Wb;
-        const int r_wy0 = (int)floorf(pcy * (float)r_H - 0.5f) - r_wh / 2 + 1;
-        const int r_wx0 = (int)floorf(pcx * (float)r_W - 0.5f) - r_ww / 2 + 1;
+        int r_Hh = r_H, r_Wh = r_W;      // (through an empty asm: their float copies are per-region temporaries, not kernel-long registers)
+        asm volatile("" : "+v"(r_Hh), "+v"(r_Wh));
+        const int r_wy0 = (int)floorf(pcy * (float)r_Hh - 0.5f) - r_wh / 2 + 1;
+        const int r_wx0 = (int)floorf(pcx * (float)r_Wh - 0.5f) - r_ww / 2 + 1;
         if (lane < KL) {
             const int ylo_ = rw_first(y0b, r_H, Hb), yhi_ = y1b >= Hb ? r_H : rw_first(y1b, r_H, Hb);
             const int xlo_ = rw_first(x0b, r_W, Wb), xhi_ = x1b >= Wb ? r_W : rw_first(x1b, r_W, Wb);
@@ -234,7 +236,11 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                     r += RPS;
                 }
             }
-            if (ocs < Wn::zrows) *reinterpret_cast<float4 *>(lds + kZ0 + ocs * 128 + j8s * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ocs < Wn::zrows) {
+                float z = 0.f;
+                asm volatile("" : "+v"(z));      // (a zero the compiler cannot keep in four registers for the whole kernel)
+                *reinterpret_cast<float4 *>(lds + kZ0 + ocs * 128 + j8s * 16) = make_float4(z, z, z, z);
+            }
             // the region's query list (slot -> pixel): worked out once here instead of by every lane in every round (~40 instructions)
             // (whole waves at a time: slot_query shuffles from lanes 0 .. KL-1, which must be active)
             if (nq_total <= kGwQList)
