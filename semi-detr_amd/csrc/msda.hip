@@ -837,7 +837,14 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         // the workgroup then owns the level's rows of its (image, head) and STORES their sums instead of adding them atomically
         // (lvl_scatter_body, "exclusive") -- micro-benchmark backward 36.3 -> 30.7 us, bs 4 / Lq 300 63 -> 53 us
         const int chunks_b = Lq <= qcap ? 1 : std::max((Lq + qcap - 1) / qcap, fine), chunk_q_b = (Lq + chunks_b - 1) / chunks_b;
-        const int chunks = std::max(std::max(chunks_b, fine), (Lq + 191) / 192);
+#ifndef SEMIDETR_LVL_CHUNKQ
+#define SEMIDETR_LVL_CHUNKQ 224      // queries per scatter workgroup of the levels too large to bucket.  Round 5 (tools/r05_ab_step.sh): the merged
+                                     // launch takes one 1024-thread workgroup per CU, so what counts is how its workgroups fill waves of 256 --
+                                     // Lq 1100 at bs 4: 192 -> 6 chunks -> 768 + 280 = 1048 workgroups = 4.09 waves; 224 / 256 -> 5 chunks -> 920 =
+                                     // 3.6: decoder backward 0.901 -> 0.864 ms per step (bs 4), 0.306 -> 0.255 (bs 1: 262 -> 230 workgroups, one
+                                     // wave); 208 (6 chunks) 0.902 / 0.306, 320 (4 chunks) 0.932 / 0.269
+#endif
+        const int chunks = std::max(std::max(chunks_b, fine), (Lq + SEMIDETR_LVL_CHUNKQ - 1) / SEMIDETR_LVL_CHUNKQ);
         const int chunk_q = (Lq + chunks - 1) / chunks;
         const int gt = (Lq + 31) / 32;                                   // gather: 32 query rows per 256-thread block
         const int64_t gblocks = (int64_t)N * gt * M, sblocks = (int64_t)N * chunks * L * M;
