@@ -78,6 +78,9 @@ constexpr int kMaxLevels = 32;
 #ifndef SEMIDETR_SCATTER_NT
 #define SEMIDETR_SCATTER_NT 512    // (704 threads = one sample per thread, no half-empty second sample slot, two workgroups per CU:
 #endif                             //  encoder backward 726 against 678 us at bs 4 -- the third workgroup is worth more)
+#ifndef SEMIDETR_SCATTER_TIGHT
+#define SEMIDETR_SCATTER_TIGHT 1
+#endif
 #ifndef SEMIDETR_SCATTER_RTH     // region scatter: region (pixels of the finest level) and window per sampling level
 // Round 5, after the flush path lost its 64-bit arithmetic (the kernel then ran at the atomic unit's rate, compute 328 of 398 us): 8 x 24
 // regions, 24 x 40 windows, 256 queries per pass, 74.5 KB of LDS = TWO workgroups per CU flush 10 % fewer rows -- 400 -> 365 us at bs 4,
@@ -808,7 +811,11 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         const size_t rlds = reg_lds_bytes<SEMIDETR_SCATTER_NT, SEMIDETR_SCATTER_Q, SEMIDETR_SCATTER_WH, SEMIDETR_SCATTER_WW>();
         if (int rc = allow_big_lds(kern, rlds, "msda_backward")) return rc;
         constexpr int kRegPix = SEMIDETR_SCATTER_RTH * SEMIDETR_SCATTER_RTW;
-        const int rbound = (S + kRegPix - 1) / kRegPix * 5 / 4 + 4 * L;
+        // grid sizing hint as for the window kernels: the finest level of a DETR pyramid holds ~3/4 of the pixels (any bound >= 1 is correct:
+        // a workgroup takes regions slot, slot + bound, ...).  The old hint (S / region * 5 / 4 + 4 L = 161 for the 91 regions of the 800 x
+        // 1333 pyramid) launched 2240 workgroups per bs-4 launch that found no region -- each holds one of a CU's two slots until it has read
+        // the level table.
+        const int rbound = SEMIDETR_SCATTER_TIGHT ? ((S * 3 / 4 + kRegPix - 1) / kRegPix) * 9 / 8 + 2 * L : (S + kRegPix - 1) / kRegPix * 5 / 4 + 4 * L;
         const int64_t rgrid = (int64_t)N * rbound * M;
         SEMIDETR_REQUIRE(rgrid < INT32_MAX, SEMIDETR_E_TOOLARGE, "msda_backward: grid too large");
         hipLaunchKernelGGL(kern, dim3((unsigned)rgrid), dim3(SEMIDETR_SCATTER_NT), rlds, st, grad_out, spatial_shapes, level_start, io, S, M, L,
