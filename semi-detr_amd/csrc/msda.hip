@@ -93,8 +93,7 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_SCATTER_WW 40
 #endif
 #ifndef SEMIDETR_GW_NT           // msda_gw_d32 (lane-per-sample gather of the encoder backward): threads, region, margins of level 0 / the coarse levels
-#define SEMIDETR_GW_NT 768
-#define SEMIDETR_GW_NT_WIDE 1024   // ... without a padding mask
+#define SEMIDETR_GW_NT 1024      // (round 5, second half: 768 -> 1024 once nothing spilled there)
 #define SEMIDETR_GW_RTH 16
 #define SEMIDETR_GW_RTW 16
 #define SEMIDETR_GW_H0 4
@@ -750,7 +749,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
             // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
             // (round 5: 1024 threads = 16 waves per CU for the reference contract and the fused prologue without a mask -- 124 / 128 VGPRs
             //  once the region grid's division reciprocals and the float copies of the level sizes are rebuilt per region: 232 -> 217 us
-            //  in the probe; the masked instantiation spills the thread index there and stays at SEMIDETR_GW_NT)
+            //  in the probe; the masked instantiation too since the thread index is rebuilt from the wave number where it is needed)
             auto launch_gw = [&](auto kern, auto nt_c) -> bool {
                 constexpr int kGwNT = decltype(nt_c)::value;
                 constexpr size_t wl = gw_lds_bytes<kGwNT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();
@@ -770,8 +769,8 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
                                               std::integral_constant<int, SEMIDETR_GW_NT>());
             }
             if (!window_gather && !io.has_mask())
-                window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT_WIDE, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false, SEMIDETR_GW_DBG>,
-                                          std::integral_constant<int, SEMIDETR_GW_NT_WIDE>());
+                window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false, SEMIDETR_GW_DBG>,
+                                          std::integral_constant<int, SEMIDETR_GW_NT>());
         }
         if (window_gather) {
         } else if (L * P == 16)             // DINO: sample loop unrolled, results in registers

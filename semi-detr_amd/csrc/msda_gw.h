@@ -76,7 +76,15 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
     int *const qlist = reinterpret_cast<int *>(lds + Wn::total * 128);                                  // the region's queries, in slot order
     char *const farl = lds + Wn::total * 128 + kGwQList * 4 + (threadIdx.x >> 6) * (kGwFarCap * 32);    // my wave's far-sample entries
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    // the thread index is rebuilt where it is needed from the wave number (a scalar register) and the lane number (two VALU): as a
+    // kernel-long vector register it was what the masked instantiation spilled at 1024 threads (the region scatter's trick, msda_region.h)
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    auto fresh_tid = [&]() {
+        unsigned ones = ~0u;
+        asm volatile("" : "+s"(ones));
+        return wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+    };
+    const int tid = fresh_tid(), lane = tid & 63;
     const int k = tid & (LP - 1), lvl = k / P;            // my sample of the row, its level
     const int Lq = S, rs = M * kD;
     const int b = (int)blockIdx.x;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             if constexpr (MASK) mask_n = io.mask + (int64_t)n * S;
             // (the thread index through an empty asm: the per-step window coordinates below depend on nothing else, and hoisted out of
             //  the region loop they are ~40 registers held for the whole kernel -- msda_rw_d32's "lean" staging)
-            int tids = tid;
+            int tids = fresh_tid();
             asm volatile("" : "+v"(tids));
             const int ocs = tids >> 3, j8s = tids & 7;
             const unsigned lane_bs = head_b + (unsigned)j8s * 16u;
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
         //  the launcher checks Lq * M * L * P * 8 < 2^32 -- instead of 64-bit multiplies by every lane in every round)
         const IO ion = io.image_view(n, Lq, M, LP);
         auto fetch = [&](int round_, Pre &p) {
-            p.q = query_of_slot(round_ * QPR + (tid >> 4));
+            p.q = query_of_slot(round_ * QPR + (fresh_tid() >> 4));
             const unsigned qs_ = p.q >= 0 ? (unsigned)p.q : 0u;       // (a lane without a query reads query 0 of the image and stores nothing)
             const unsigned row_ = qs_ * (unsigned)M + (unsigned)m;
             p.rxy = ion.load_xy_raw(row_, qs_, LP, k, lvl);
