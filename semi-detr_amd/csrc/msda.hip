@@ -128,6 +128,9 @@ constexpr int kMaxLevels = 32;
                                  // + 1600: the fused prologue's location arithmetic at the start of the round that uses the loaded data, not
                                  // where the loads are issued (a round early, waiting for them): fused-prologue forward 189.8 -> 188.0 us
 #endif
+#ifndef SEMIDETR_RW_SB_LOCATTN
+#define SEMIDETR_RW_SB_LOCATTN 20     // added to SEMIDETR_RW_TUNE for the reference contract: 10 x (samples between barriers - 2)
+#endif
 #ifndef SEMIDETR_RW_TUNE_MASK
 #define SEMIDETR_RW_TUNE_MASK 98320   // the instantiation with the padding mask (166 VGPRs; with the table but without the compact records it spills)
 #endif
@@ -664,6 +667,9 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             };
             auto pick_window = [&]() -> int {
                 constexpr int kTune5 = std::is_same<IO, RawIO>::value ? SEMIDETR_RW_TUNE5_RAW : SEMIDETR_RW_TUNE5;
+                // (the reference contract's main instantiation has the registers for FOUR samples between scheduling barriers since the
+                //  compact records -- 168 VGPRs, no spill: -1.3 ... -2 % in the probe; the fused prologue's and the tail-split ones spill there)
+                constexpr int kTune4 = std::is_same<IO, RawIO>::value ? SEMIDETR_RW_TUNE : SEMIDETR_RW_TUNE + SEMIDETR_RW_SB_LOCATTN;
                 constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, SEMIDETR_RW_TUNE>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, kTune5>();
                 static_assert(wlds4 <= 160 * 1024 && wlds5 <= 160 * 1024, "region-window configuration does not fit the LDS");
                 if constexpr (std::is_same<IO, RawIO>::value) {
@@ -681,7 +687,7 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
                     }
                 }
                 if (L == 4)
-                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE>,
+                    return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, kTune4>,
                                          &msda_rw_d32<IO, SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, false, SEMIDETR_RW_DBG, SEMIDETR_RW_TUNE + 102400>, wlds4,
                                          SEMIDETR_RW_NT, SEMIDETR_RW_RTH * 16);
                 return launch_window(&msda_rw_d32<IO, SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, false, 0, kTune5>, nullptr, wlds5, SEMIDETR_RW_NT5,
