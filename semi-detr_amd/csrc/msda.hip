@@ -734,7 +734,8 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     const bool pixels = (flags & SEMIDETR_MSDA_QUERIES_ARE_PIXELS) != 0 && (size_t)32 * (L * P + 1) * 32 <= 63 * 1024;
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     // (S * M * 128 < 2^32: the region scatter addresses grad_value rows by 32-bit byte offsets from the image's first row)
-    if (pixels && P == kPT && S < (1 << 23) && (uint64_t)S * M * kD * 4 < (1ull << 32)) {
+    // (... and its sampling data inside the image's view with 32-bit indices: S * M * L * P * 8 < 2^32)
+    if (pixels && P == kPT && S < (1 << 23) && (uint64_t)S * M * kD * 4 < (1ull << 32) && (uint64_t)S * M * L * P * 8 < (1ull << 32)) {
         // ---- encoder self-attention: patch gather (the two small gradients; it clears grad_value as a side job, the
         //      scatter that accumulates into it is the NEXT launch) + region-owned scatter (msda_region.h)
         const bool fill_in_gather = (L * P == 16 || L * P == 20) && (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0;

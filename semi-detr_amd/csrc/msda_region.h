@@ -151,7 +151,13 @@ __device__ __forceinline__ void reg_scatter_body(
             __syncthreads();
             // this thread's samples = (slot i, point p), sample index tid + sp * NT
             int qs[SPT];
-            auto srow_of = [&](int q) { return ((int64_t)n * Lq + q) * M + m; };      // recomputed: two registers fewer per sample
+            // (rows inside MY image, 32-bit: the image's view of the sampling tensors `ion` -- the launcher checks that an image's sampling data
+            //  stay below 2^32 bytes; the fused-backward experiment keeps the batch-wide 64-bit rows for its stores)
+            auto srow_of = [&](int q) {
+                if constexpr (FUSE == 0) return (unsigned)q * (unsigned)M + (unsigned)m;
+                else return ((int64_t)n * Lq + q) * M + m;
+            };      // recomputed: two registers fewer per sample
+            const IO ion = FUSE == 0 ? io.image_view(n, Lq, M, LP) : io;
             float sm_max[SPT], sm_inv[SPT];
             float dotsum[SPT];               // FUSE + fused prologue: sum over the levels of a_k * d/d a_k (softmax backward)
 #pragma unroll
@@ -167,12 +173,12 @@ __device__ __forceinline__ void reg_scatter_body(
                     // in one quad (P == 4): two DPP steps per reduction.  __expf as in the forward / gather (row_softmax), so
                     // the three kernels of an op agree on the weights to the last bit.
                     constexpr int kLv = 8;       // levels held in registers (pyramids beyond that take the loops)
-                    const int64_t srow = srow_of(qs[sp] >= 0 ? qs[sp] : qlist[0]);
+                    const auto srow = srow_of(qs[sp] >= 0 ? qs[sp] : qlist[0]);
                     float mx, sum = 0.f;
                     if (L <= kLv) {
                         float lg[kLv];
 #pragma unroll
-                        for (int l = 0; l < kLv; ++l) lg[l] = l < L ? io.load_w(srow, LP, l * P + p) : -__builtin_huge_valf();
+                        for (int l = 0; l < kLv; ++l) lg[l] = l < L ? ion.load_w(srow, LP, l * P + p) : -__builtin_huge_valf();
                         mx = lg[0];
 #pragma unroll
                         for (int l = 1; l < kLv; ++l) mx = fmaxf(mx, lg[l]);
@@ -182,10 +188,10 @@ __device__ __forceinline__ void reg_scatter_body(
                         for (int l = 0; l < kLv; ++l) sum += l < L ? __expf(lg[l] - mx) : 0.f;
                     } else {
                         mx = -__builtin_huge_valf();
-                        for (int l = 0; l < L; ++l) mx = fmaxf(mx, io.load_w(srow, LP, l * P + p));
+                        for (int l = 0; l < L; ++l) mx = fmaxf(mx, ion.load_w(srow, LP, l * P + p));
                         mx = fmaxf(mx, dpp_mov<0xB1>(mx));
                         mx = fmaxf(mx, dpp_mov<0x4E>(mx));
-                        for (int l = 0; l < L; ++l) sum += __expf(io.load_w(srow, LP, l * P + p) - mx);
+                        for (int l = 0; l < L; ++l) sum += __expf(ion.load_w(srow, LP, l * P + p) - mx);
                     }
                     sum += dpp_mov<0xB1>(sum);
                     sum += dpp_mov<0x4E>(sum);
@@ -236,9 +242,10 @@ __device__ __forceinline__ void reg_scatter_body(
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
                     const int k = l * P + (tid + sp * NT) % P, qq = qs[sp] >= 0 ? qs[sp] : qlist[0];
-                    const int64_t srow = srow_of(qq);
-                    io.load_xy(srow, (int64_t)n * Lq + qq, LP, k, l, P, H, W, gx[sp], gy[sp]);
-                    ga[sp] = io.load_w(srow, LP, k);
+                    const auto srow = srow_of(qq);
+                    if constexpr (FUSE == 0) ion.load_xy(srow, (unsigned)qq, LP, k, l, P, H, W, gx[sp], gy[sp]);
+                    else ion.load_xy(srow, (int64_t)n * Lq + qq, LP, k, l, P, H, W, gx[sp], gy[sp]);
+                    ga[sp] = ion.load_w(srow, LP, k);
                 }
 #pragma unroll
                 for (int sp = 0; sp < SPT; ++sp) {
@@ -247,7 +254,8 @@ __device__ __forceinline__ void reg_scatter_body(
                     int h0 = 0, w0 = 0;
                     if (qs[sp] >= 0) {
                         const float x = gx[sp], y = gy[sp];
-                        if (sample_setup(x, y, H, W, st, rs, off, lw, lh)) {
+                        // (only the SIGNS of off[] are used below -- which corners exist: start 1 and stride 1 keep them and drop the multiplies)
+                        if (sample_setup(x, y, H, W, 1, 1, off, lw, lh)) {
                             a = ga[sp];
                             if (IO::kSoftmax) a = __expf(a - sm_max[sp]) * sm_inv[sp];
                             h0 = (int)floorf(sub_rn(mul_rn(y, (float)H), 0.5f));
