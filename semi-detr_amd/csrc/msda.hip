@@ -738,7 +738,10 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     if (pixels && P == kPT && S < (1 << 23) && (uint64_t)S * M * kD * 4 < (1ull << 32) && (uint64_t)S * M * L * P * 8 < (1ull << 32)) {
         // ---- encoder self-attention: patch gather (the two small gradients; it clears grad_value as a side job, the
         //      scatter that accumulates into it is the NEXT launch) + region-owned scatter (msda_region.h)
-        const bool fill_in_gather = (L * P == 16 || L * P == 20) && (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0;
+#ifndef SEMIDETR_SEPARATE_FILL
+#define SEMIDETR_SEPARATE_FILL 0      // tuning builds: 1 = hipMemsetAsync before the gather instead of the gather's side job
+#endif
+        const bool fill_in_gather = !SEMIDETR_SEPARATE_FILL && (L * P == 16 || L * P == 20) && (reinterpret_cast<uintptr_t>(grad_value) & 15) == 0;
         if (!fill_in_gather) {
             const hipError_t e = hipMemsetAsync(grad_value, 0, fill, st);
             if (e != hipSuccess) return semidetr::fail((int)e, "msda_backward memset: %s", hipGetErrorString(e));
@@ -751,7 +754,7 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         bool window_gather = false;
         // (SEMIDETR_MSDA_FIXED_FORWARD: which gather runs must not depend on earlier launches either -- the patch gather)
         // (Lq * M * L * P * 8 bytes per image < 2^32: msda_gw_d32 indexes the sampling data inside an image with 32 bits)
-        if (L == 4 && P == kPT && fill_in_gather && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff) &&
+        if (L == 4 && P == kPT && (fill_in_gather || SEMIDETR_SEPARATE_FILL) && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff) &&
             (uint64_t)Lq * M * L * P * 8 < (1ull << 32)) {
             // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
             // (round 5: 1024 threads = 16 waves per CU for the reference contract and the fused prologue without a mask -- 124 / 128 VGPRs
