@@ -96,6 +96,27 @@ def test_window_forward_full_size_vs_oracle(io, levels):
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("io", ["locattn", "raw"])
+@pytest.mark.parametrize("N", [1, 2])
+def test_window_forward_tail_split_full_size_vs_oracle(io, N):
+    """Round 5: launches of fewer than ~three waves of workgroups run the instantiation with the TAIL SPLIT (msda_rw.h, TUNE + 102400) --
+    one image is 352 (image, head, region) units on 256 CUs: the last 96 are cut into two parts of their rounds, the second parts
+    taken by helper workgroups; two images are 704 units, 192 in the tail.  Every element against the oracle."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd as sda
+    value, shp, ref, off, logits, _ = _encoder_case(N, LEVELS, 2.0, 31 + N)
+    loc, attn = _prologue_np(ref, off, logits, shp, P)
+    want = oracle.msda_forward(value, shp, loc, attn)
+    tsh = _t(shp)
+    sda._lib.set_forward_policy("window")
+    if io == "locattn":
+        out = MSDA.ms_deform_attn_forward(_t(value), tsh, _starts(tsh), _t(loc), _t(attn), 64)
+    else:
+        out = MSDA.ms_deform_attn_fused_forward(_t(value), tsh, _starts(tsh), _t(ref), _t(off), _t(logits))
+    assert _last() == "msda_rw_d32"
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=2e-6)
+
+
 def test_window_policy_keeps_the_patch_kernel_where_the_window_kernel_does_not_apply():
     """Six levels: policy "window" must fall back to the patch kernel (and give its results)."""
     import MultiScaleDeformableAttention as MSDA
