@@ -20,8 +20,9 @@
 #pragma once
 
 // NT threads; kRegQ queries per pass; region = RTH x RTW pixels of the finest level; WH x WW window per sampling level.
-// Two configurations are instantiated: <1024, 384, 16, 16, 32, 32> (one workgroup per CU) and <512, 208, 8, 16, 24, 32>
-// (two per CU: the phases of one hide the barriers of the other).
+// Product (round 5): <512, 256, 8, 24, 24, 40> -- 8 x 24 regions, two workgroups per CU (74.5 KB of LDS each; the phases of one hide the
+// barriers of the other).  Rounds 2-4 ran <512, 208 / 176, 8, 16, 24, 32> at two / three per CU: the optimum while the walk's compute
+// was a co-limit; with the cheap flush path the atomic unit binds and fewer flushed rows win (msda.hip SEMIDETR_SCATTER_*).
 template <int NT, int kRegQ, int WH, int WW, int FUSE = 0>
 constexpr size_t reg_lds_bytes()
 {
