@@ -930,14 +930,17 @@ def main():
     ap.add_argument("--recipe", default="coco10", choices=sorted(RECIPES),
                     help="coco10: BASELINE.json configs[2]/[3] (1 labeled + 4 unlabeled per GPU, 4 levels); full: configs[4] "
                          "(COCO-Full: 4 labeled + 4 unlabeled per GPU, 5 feature levels)")
-    ap.add_argument("--io", default="locattn", choices=["locattn", "raw"],
-                    help="locattn: the reference op contract (sampling locations + softmaxed weights); raw: the fused "
-                         "MSDeformAttn prologue / epilogue the product module runs by default (reference points + raw offsets "
-                         "+ raw logits)")
-    ap.add_argument("--masked", action="store_true",
-                    help="images of different sizes on the 800 x 1333 canvas: every MSDeformAttn call gets its batch's padding mask "
-                         "and valid-ratio scaled reference points, as the reference's transformer passes them (locattn: masked_fill "
-                         "around the op, ms_deform_attn.py:95-96; raw: the mask goes into the fused kernels)")
+    ap.add_argument("--io", default="raw", choices=["locattn", "raw"],
+                    help="raw (default = what a checkout runs: the product's MSDeformAttn has fuse_prologue=True): the fused "
+                         "MSDeformAttn prologue / epilogue (reference points + raw offsets + raw logits); locattn: the reference op "
+                         "contract (sampling locations + softmaxed weights) with the prologue outside the timed region")
+    ap.add_argument("--masked", dest="masked", action="store_true", default=True,
+                    help="(default) images of different sizes on the 800 x 1333 canvas: every MSDeformAttn call gets its batch's "
+                         "padding mask and valid-ratio scaled reference points, as the reference's transformer passes them "
+                         "(transformer.py:1268-1309; locattn: masked_fill around the op, ms_deform_attn.py:95-96; raw: the mask goes "
+                         "into the fused kernels)")
+    ap.add_argument("--unmasked", dest="masked", action="store_false",
+                    help="no padding mask, reference points unscaled (the headline of rounds 1-5; no reference config calls the op so)")
     ap.add_argument("--reuse-encoder", action="store_true",
                     help="NOT the reference's call structure (INTEGRATION.md 3.3): the student's and the teacher's second encoder "
                          "pass over identical inputs reuse the first one's memory -- 12 fewer unlabeled-batch encoder forwards")
@@ -1126,7 +1129,8 @@ def main():
                                       wl.n_sup, wl.n_unsup, wl.S, wl.L, wl.S, wl.n_match, wl.n_params),
                        "recipe": args.recipe, "io": args.io, "masked": bool(args.masked), "images_per_gpu": ipg, "reuse_encoder": bool(args.reuse_encoder),
                        "backbone_ms": args.backbone_ms, "input_sets_per_group": wl.rot, "forward_policy": args.forward_policy,
-                       "parallelism": "dp%d image-sharded, FlatDDP bucketed grad all-reduce of %d fp32 over RCCL" % (world, GRAD_ELEMS)
+                       "parallelism": "dp%d image-sharded, FlatDDP bucketed grad all-reduce of %d fp32 over %s"
+                                      % (world, GRAD_ELEMS, {"nccl": "RCCL (torch backend nccl)"}.get(dist.get_backend(), dist.get_backend()))
                        if world > 1 else "single GPU"},
             "roofline": roofline_of(dom_name),
             "roofline_largest_group": roofline_of(big_name) if big_name != dom_name else None,
@@ -1153,7 +1157,8 @@ def main():
                         "last MSDA backward launch, so its reduction is NOT overlapped (pessimistic: in training the backbone's "
                         "backward runs behind it); --backbone-ms X puts a device-side sleep of X ms there, the backbone's "
                         "parameters becoming ready in four slices (realistic)"}
-        if world == 1 and not args.no_micro and args.recipe == "coco10" and args.io == "locattn":      # single-GPU extras
+        headline_cfg = args.recipe == "coco10" and args.io == "raw" and args.masked and not args.reuse_encoder
+        if world == 1 and not args.no_micro and headline_cfg:      # single-GPU extras
             # BASELINE.json config 2: supervised DINO-R50 bs 2 (hot path only), its own timed loop
             for _ in range(2):
                 wl.sup_step()
@@ -1186,30 +1191,34 @@ def main():
             out["encoder_forward_by_sample_spread"] = forward_policy_bench(dev)
             out["module_fused_prologue"] = module_bench(dev)
             out["warmup_stage"] = warmup_stage_bench(dev)
-        if world == 1 and not args.no_flavours and args.recipe == "coco10" and args.io == "locattn" and not args.reuse_encoder and not args.masked:
+        if world == 1 and not args.no_flavours and headline_cfg:
             # the other flavours of the step, 5 steps each (the driver's record then answers "COCO-Full images/s" and
-            # "fused-path images/s" by itself); the headline above stays the reference-contract COCO-10 % step
+            # "reference-contract images/s" by itself); the headline above is the PRODUCT DEFAULT: fused prologue + padding mask
             del wl.t
             torch.cuda.empty_cache()
-            out["flavours"] = {"raw": run_flavour(dev, 1234, "coco10", "raw"),
-                               "raw_masked": run_flavour(dev, 1234, "coco10", "raw", masked=True),
+            out["flavours"] = {"locattn": run_flavour(dev, 1234, "coco10", "locattn"),
+                               "raw": run_flavour(dev, 1234, "coco10", "raw"),
                                "masked": run_flavour(dev, 1234, "coco10", "locattn", masked=True),
                                "full": run_flavour(dev, 1234, "full", "locattn"),
                                "full_raw": run_flavour(dev, 1234, "full", "raw"),
-                               "reuse_encoder": run_flavour(dev, 1234, "coco10", "locattn", reuse_encoder=True),
+                               "full_raw_masked": run_flavour(dev, 1234, "full", "raw", masked=True),
+                               "reuse_encoder": run_flavour(dev, 1234, "coco10", "raw", reuse_encoder=True, masked=True),
                                "replayed_inputs": run_flavour(dev, 1234, "coco10", "locattn", input_sets=1)}
-            out["flavours"]["note"] = ("raw = the fused MSDeformAttn prologue kernels the product module runs by default; raw_masked = the "
-                                       "same with what the reference's transformer really passes: the padding mask of a batch of images of "
-                                       "different sizes in every call (inside the fused kernels) and valid-ratio scaled reference points "
-                                       "-- what a checkout with unchanged configs runs; masked = that batch through the reference op "
-                                       "contract, value.masked_fill(mask, 0) before the op and its backward after it "
-                                       "(ms_deform_attn.py:95-96); full = "
-                                       "COCO-Full recipe (BASELINE.json configs[4]: 4 + 4 images, five levels); reuse_encoder = the "
-                                       "call-site change of INTEGRATION.md 3.3 (12 fewer encoder forwards), NOT the reference's call "
-                                       "structure; replayed_inputs = the headline step with ONE input set per group replayed by all six "
-                                       "layers (--input-sets 1), the methodology of rounds 1-3: the value map of a group then stays in the "
-                                       "Infinity Cache between launches, which a training step -- six layers, six activations -- does "
-                                       "not offer; comparable with BENCH_r01..r03, not with the headline of this line")
+            out["flavours"]["note"] = ("HEADLINE (value / ms_per_step / roofline of this line) = raw_masked: the fused MSDeformAttn "
+                                       "prologue kernels the product module runs by default, with what the reference's transformer "
+                                       "really passes -- the padding mask of a batch of images of different sizes in every call (inside "
+                                       "the fused kernels) and valid-ratio scaled reference points: what a checkout with unchanged "
+                                       "configs runs.  locattn = the reference OP contract on unmasked inputs with the prologue (softmax, "
+                                       "location arithmetic, masked_fill) outside the timed region -- the headline of rounds 1-5, a call "
+                                       "nobody makes; raw = the fused kernels without a mask; masked = the padded batch through the "
+                                       "reference op contract, value.masked_fill(mask, 0) before the op and its backward after it "
+                                       "(ms_deform_attn.py:95-96) -- what a checkout that swaps only the native module runs; full = "
+                                       "COCO-Full recipe (BASELINE.json configs[4]: 4 + 4 images, five levels), reference contract; "
+                                       "full_raw / full_raw_masked = the same through the fused kernels without / with the mask; "
+                                       "reuse_encoder = the call-site change of INTEGRATION.md 3.3 (12 fewer encoder forwards) on the "
+                                       "headline configuration, NOT the reference's call structure; replayed_inputs = the locattn step "
+                                       "with ONE input set per group replayed by all six layers (--input-sets 1), the methodology of "
+                                       "rounds 1-3: comparable with BENCH_r01..r03 only")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out))

@@ -551,10 +551,12 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, F
     if (!g_adapt[dev]) return SEMIDETR_OK;
     FwdAdapt &a = *g_adapt[dev];
     if (!a.dev_cnt && !a.failed && !capturing) {       // first use on this device (never inside a stream capture): two small
-        // allocations (these calls may synchronise the device ONCE per process and device) and a clear queued on the launch's stream
+        // allocations and a SYNCHRONOUS clear (ONCE per process and device; the allocations may synchronise anyway).  The counter block
+        // is shared by every slot and every stream of the device: a clear merely queued on the first launch's stream could run after
+        // another stream's first counting launch had started adding.
         void *h = nullptr, *d = nullptr, *c = nullptr;
         if (hipHostMalloc(&h, kPolicySlots * 16, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess &&
-            hipMalloc(&c, kPolicySlots * 64) == hipSuccess && hipMemsetAsync(c, 0, kPolicySlots * 64, st) == hipSuccess) {
+            hipMalloc(&c, kPolicySlots * 64) == hipSuccess && hipMemset(c, 0, kPolicySlots * 64) == hipSuccess) {
             std::fill_n(static_cast<unsigned *>(h), kPolicySlots * 4, 0u);
             a.pub_host = static_cast<unsigned *>(h);
             a.pub_dev = static_cast<unsigned *>(d);
@@ -735,7 +737,10 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
     const size_t fill = sizeof(float) * (size_t)N * S * M * kD;
     // (S * M * 128 < 2^32: the region scatter addresses grad_value rows by 32-bit byte offsets from the image's first row)
     // (... and its sampling data inside the image's view with 32-bit indices: S * M * L * P * 8 < 2^32)
-    if (pixels && P == kPT && S < (1 << 23) && (uint64_t)S * M * kD * 4 < (1ull << 32) && (uint64_t)S * M * L * P * 8 < (1ull << 32)) {
+    // (M * 128 <= 0xffff: the region scatter's flush multiplies a 16-bit pixel key by the row pitch into 32 bits -- implied by heads_ok,
+    //  stated here because the kernel's inline assembly depends on it)
+    if (pixels && P == kPT && S < (1 << 23) && (uint64_t)S * M * kD * 4 < (1ull << 32) && (uint64_t)S * M * L * P * 8 < (1ull << 32) &&
+        (int64_t)M * kD * 4 <= 0xffff) {
         // ---- encoder self-attention: patch gather (the two small gradients; it clears grad_value as a side job, the
         //      scatter that accumulates into it is the NEXT launch) + region-owned scatter (msda_region.h)
 #ifndef SEMIDETR_SEPARATE_FILL

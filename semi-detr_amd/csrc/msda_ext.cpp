@@ -283,7 +283,14 @@ at::Tensor mask_extents(const at::Tensor &m, const at::Tensor &shapes, const at:
                     shapes.is_contiguous() && starts.is_contiguous() && shapes.dim() == 2 && shapes.size(1) == 2 &&
                     starts.numel() == shapes.size(0),
                 "mask_extents: expected contiguous int64 spatial_shapes (L,2) and level_start_index (L,) on the mask's device");
+    // (the kernel indexes mask[n * S + starts[l] + i] for i < H * W -- the level table has to be on the mask's device
+    //  and has to describe exactly S pixels; the cached pyramid check answers that without a copy after the first call)
+    TORCH_CHECK(shapes.device() == m.device() && starts.device() == m.device(),
+                "mask_extents: spatial_shapes / level_start_index must be on the mask's device");
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(m.device());
+    TORCH_CHECK((pyramid_check(shapes, starts, m.size(1)) & 1) != 0,
+                "mask_extents: sum(H * W) of spatial_shapes must equal padding_mask.size(1) (and level_start_index must be readable "
+                "outside a stream capture)");
     void *stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(m.device().index()).stream();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;

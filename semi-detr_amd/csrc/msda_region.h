@@ -505,7 +505,12 @@ __device__ __forceinline__ void reg_scatter_body(
                         if ((AID & 2) && accv.x != 1.2345e30f) return;
                         if constexpr (kPixKey) {
                             // byte offset of the lane's first channel from the window's first pixel: one 24-bit multiply-add; the two
-                            // half-line atomics take the scalar base (the instructions fp_atomic_add compiles to, saddr form)
+                            // half-line atomics take the scalar base (the instructions fp_atomic_add compiles to, saddr form).
+                            // 16-bit key x row pitch must stay below 2^32: M * 128 <= 4096 on every fast-path launch (heads_ok, msda.hip;
+                            // launch_fast_backward repeats the bound next to this kernel's launch -- ADVICE r05).  gfx9 encodings.
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "msda_region.h: the flush path is written in gfx9 (CDNA) assembly"
+#endif
                             unsigned voff;
                             asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(voff) : "v"(rowi | 0x8000), "s"(rs4), "v"(lane4));
                             asm volatile("global_atomic_add_f32 %0, %1, %3\n\tglobal_atomic_add_f32 %0, %2, %3 offset:64"

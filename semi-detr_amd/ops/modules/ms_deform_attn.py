@@ -28,6 +28,10 @@ def _is_power_of_2(n):
 _policy_slots = itertools.count(1)
 
 
+def _next_policy_slot():
+    return (next(_policy_slots) - 1) % 255 + 1
+
+
 class MSDeformAttn(nn.Module):
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
@@ -46,7 +50,7 @@ class MSDeformAttn(nn.Module):
         # Which of the two encoder forward kernels runs follows how far THIS instance's learned offsets reach (semidetr_hip.h:
         # SEMIDETR_MSDA_POLICY_SLOT): instances take consecutive slots 1..255 (the reference builds 12 per model,
         # transformer.py:609,760; beyond 255 instances slots are shared, which only mixes their counts).  Plain attribute.
-        self.policy_slot = (next(_policy_slots) - 1) % 255 + 1
+        self.policy_slot = _next_policy_slot()
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
 
         self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
@@ -54,6 +58,14 @@ class MSDeformAttn(nn.Module):
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
         self._reset_parameters()
+
+    def __setstate__(self, state):
+        # copy.deepcopy (an EMA teacher cloned from the student) and unpickling (torch.save(model), checkpoints that pickle modules)
+        # both come through here: the copy is its own call site with its own learned offsets, so it takes a FRESH slot -- sharing
+        # the original's would mix the two instances' sample-spread counts; a module pickled before the attribute existed gets one too
+        super().__setstate__(state)
+        self.__dict__["policy_slot"] = _next_policy_slot()
+        self.__dict__.setdefault("fuse_prologue", True)
 
     def _reset_parameters(self):
         # ms_deform_attn.py:62-76 -- head m looks along direction 2*pi*m/M, point i at distance i+1
@@ -98,7 +110,7 @@ class MSDeformAttn(nn.Module):
             output = MSDeformAttnFusedFunction.apply(value.contiguous(), input_spatial_shapes,
                                                      input_level_start_index, reference_points.contiguous(),
                                                      offsets.contiguous(), logits.contiguous(), input_padding_mask,
-                                                     self.policy_slot)
+                                                     getattr(self, "policy_slot", 0))
             return self.output_proj(output)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None, None], float(0))
@@ -115,8 +127,8 @@ class MSDeformAttn(nn.Module):
 
         if value.dtype == torch.float16:      # amp: the op itself runs in fp32 (ms_deform_attn.py:114-120)
             output = MSDeformAttnFunction.apply(value.float(), input_spatial_shapes, input_level_start_index,
-                                                locations.float(), weights.float(), self.im2col_step, self.policy_slot)
+                                                locations.float(), weights.float(), self.im2col_step, getattr(self, "policy_slot", 0))
             return self.output_proj(output.to(torch.float16))
         output = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
-                                            locations.contiguous(), weights.contiguous(), self.im2col_step, self.policy_slot)
+                                            locations.contiguous(), weights.contiguous(), self.im2col_step, getattr(self, "policy_slot", 0))
         return self.output_proj(output)
