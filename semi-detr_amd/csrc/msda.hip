@@ -31,8 +31,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #if SEMIDETR_EXPERIMENTS
@@ -99,6 +101,11 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_GW_H0 4
 #define SEMIDETR_GW_HC 4
 #endif
+#ifndef SEMIDETR_GW_RTH5
+#define SEMIDETR_GW_RTH5 13      // ... five levels: the windows of all five at margin 4 fit beside the query list with regions of up to 13 x 16 pixels
+#define SEMIDETR_GW_NT5 1024     //     (a 100-row level = 8 x 12.5 rows; 14 rows -- the same tiling -- would need 165 KB)
+#define SEMIDETR_GW_NT5_RAW 768  //     the fused prologue's five-level instantiations spill 4 / 9 vector registers at 1024 threads (128 VGPRs)
+#endif
 #ifndef SEMIDETR_GW_FB
 #define SEMIDETR_GW_FB 4         // msda_gw_d32: far samples whose loads are in flight together
 #endif
@@ -129,7 +136,9 @@ constexpr int kMaxLevels = 32;
                                  // where the loads are issued (a round early, waiting for them): fused-prologue forward 189.8 -> 188.0 us
 #endif
 #ifndef SEMIDETR_RW_SB_LOCATTN
-#define SEMIDETR_RW_SB_LOCATTN 20     // added to SEMIDETR_RW_TUNE for the reference contract: 10 x (samples between barriers - 2)
+#define SEMIDETR_RW_SB_LOCATTN 10     // added to SEMIDETR_RW_TUNE for the reference contract: 10 x (samples between barriers - 2).  Round 6: THREE samples
+                                      // (four sit exactly at 168 VGPRs and spilled 8 once FwdStats became one pointer; three and four measured level in round 5:
+                                      //  163.1 / 169.8 / 190.4 against 163.9 / 169.2 / 188.1 us at sigma 1 / 2 / 3 px, profiles/r05_forward_timing_aids.txt section 8)
 #endif
 #ifndef SEMIDETR_RW_TUNE_MASK
 #define SEMIDETR_RW_TUNE_MASK 98320   // the instantiation with the padding mask (166 VGPRs; with the table but without the compact records it spills)
@@ -538,7 +547,7 @@ int device_cus()
 
 int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, FwdStats &fs, bool &use_window)
 {
-    fs = FwdStats{nullptr, nullptr, nullptr, nullptr};
+    fs = FwdStats{nullptr, 0u};
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
     use_window = allow_window && policy == 2;
     if (policy != 0 || !allow_window) return SEMIDETR_OK;
@@ -555,8 +564,16 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, F
         // is shared by every slot and every stream of the device: a clear merely queued on the first launch's stream could run after
         // another stream's first counting launch had started adding.
         void *h = nullptr, *d = nullptr, *c = nullptr;
+        // (the device block of a slot: counters zero, words [10..11] = where the slot's record lives in the mapped host memory -- FwdStats)
+        std::vector<unsigned> init((size_t)kPolicySlots * 16, 0u);
         if (hipHostMalloc(&h, kPolicySlots * 16, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess &&
-            hipMalloc(&c, kPolicySlots * 64) == hipSuccess && hipMemset(c, 0, kPolicySlots * 64) == hipSuccess) {
+            hipMalloc(&c, kPolicySlots * 64) == hipSuccess) {
+            for (int sid = 0; sid < kPolicySlots; ++sid) {
+                const unsigned *pp = static_cast<unsigned *>(d) + 4 * sid;
+                std::memcpy(&init[(size_t)sid * 16 + 10], &pp, sizeof(pp));
+            }
+        }
+        if (h && d && c && hipMemcpy(c, init.data(), init.size() * sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess) {
             std::fill_n(static_cast<unsigned *>(h), kPolicySlots * 4, 0u);
             a.pub_host = static_cast<unsigned *>(h);
             a.pub_dev = static_cast<unsigned *>(d);
@@ -586,7 +603,7 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, F
         if (!capturing) {                              // a captured launch keeps the kernel of the moment and counts nothing
             const unsigned par = sl.launches++ & 1u;
             unsigned *base = a.dev_cnt + 16 * sid;
-            fs = FwdStats{base + 4 * par, base + 4 * (1 - par), a.pub_dev + 4 * sid, base + 8};
+            fs = FwdStats{base, par};
         }
     }
     use_window = sl.mode == 1;
@@ -669,7 +686,7 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             };
             auto pick_window = [&]() -> int {
                 constexpr int kTune5 = std::is_same<IO, RawIO>::value ? SEMIDETR_RW_TUNE5_RAW : SEMIDETR_RW_TUNE5;
-                // (the reference contract's main instantiation has the registers for FOUR samples between scheduling barriers since the
+                // (the reference contract's main instantiation has the registers for THREE (round 5: four) samples between scheduling barriers since the
                 //  compact records -- 168 VGPRs, no spill: -1.3 ... -2 % in the probe; the fused prologue's and the tail-split ones spill there)
                 constexpr int kTune4 = std::is_same<IO, RawIO>::value ? SEMIDETR_RW_TUNE : SEMIDETR_RW_TUNE + SEMIDETR_RW_SB_LOCATTN;
                 constexpr size_t wlds4 = rw_lds_bytes<SEMIDETR_RW_NT, SEMIDETR_RW_RTH, 16, -1, SEMIDETR_RW_HC, 4, SEMIDETR_RW_TUNE>(), wlds5 = rw_lds_bytes<SEMIDETR_RW_NT5, SEMIDETR_RW_RTH5, 16, -1, 4, 5, kTune5>();
@@ -698,7 +715,7 @@ int launch_fast_forward(hipStream_t st, const float *value, const int64_t *spati
             const int wrc = pick_window();
             if (!fell_back) return wrc;
             (void)hipGetLastError();
-            fs = FwdStats{nullptr, nullptr, nullptr, nullptr};      // (this launch's counter parity was the window kernel's: count nothing)
+            fs = FwdStats{nullptr, 0u};      // (this launch's counter parity was the window kernel's: count nothing)
         }
         // 4 x 8 query patches.  Grid sizing hint: about the number of 32-pixel patches of a usual pyramid (ragged edges
         // included); a workgroup takes patches slot, slot + hint, ... so any hint >= 1 is correct
@@ -759,33 +776,42 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         bool window_gather = false;
         // (SEMIDETR_MSDA_FIXED_FORWARD: which gather runs must not depend on earlier launches either -- the patch gather)
         // (Lq * M * L * P * 8 bytes per image < 2^32: msda_gw_d32 indexes the sampling data inside an image with 32 bits)
-        if (L == 4 && P == kPT && (fill_in_gather || SEMIDETR_SEPARATE_FILL) && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff) &&
+        if ((L == 4 || L == 5) && P == kPT && (fill_in_gather || SEMIDETR_SEPARATE_FILL) && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff) &&
             (uint64_t)Lq * M * L * P * 8 < (1ull << 32)) {
             // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
             // (round 5: 1024 threads = 16 waves per CU for the reference contract and the fused prologue without a mask -- 124 / 128 VGPRs
             //  once the region grid's division reciprocals and the float copies of the level sizes are rebuilt per region: 232 -> 217 us
             //  in the probe; the masked instantiation too since the thread index is rebuilt from the wave number where it is needed)
-            auto launch_gw = [&](auto kern, auto nt_c) -> bool {
+            // Five levels (round 6, the COCO-Full pyramid): 20 lanes per (query, head) row, three rows per wave; the windows of five levels
+            // at margin 4 fit the LDS with regions of up to 13 x 16 pixels (SEMIDETR_GW_RTH5).
+            auto launch_gw = [&](auto kern, auto nt_c, size_t wl, int region_px) -> bool {
                 constexpr int kGwNT = decltype(nt_c)::value;
-                constexpr size_t wl = gw_lds_bytes<kGwNT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();
                 if (allow_big_lds(kern, wl, "msda_backward") != SEMIDETR_OK) {      // refused: the patch gather below
                     (void)hipGetLastError();
                     return false;
                 }
-                const int wbound = ((S * 3 / 4 + SEMIDETR_GW_RTH * SEMIDETR_GW_RTW - 1) / (SEMIDETR_GW_RTH * SEMIDETR_GW_RTW)) * 9 / 8 + 2 * L;
+                const int wbound = ((S * 3 / 4 + region_px - 1) / region_px) * 9 / 8 + 2 * L;
                 if ((int64_t)N * wbound * M >= INT32_MAX) return false;
                 hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)N * wbound * M)), dim3(kGwNT), wl, st, grad_out, value, spatial_shapes,
                                    level_start, io, S, M, wbound, zero, (int64_t)(fill / 16));
                 return true;
             };
+            constexpr int kNT5 = std::is_same<IO, RawIO>::value ? SEMIDETR_GW_NT5_RAW : SEMIDETR_GW_NT5;
+            constexpr size_t wl4 = gw_lds_bytes<SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4>();
+            constexpr size_t wl5 = gw_lds_bytes<kNT5, SEMIDETR_GW_RTH5, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 5>();
+            constexpr int px4 = SEMIDETR_GW_RTH * SEMIDETR_GW_RTW, px5 = SEMIDETR_GW_RTH5 * SEMIDETR_GW_RTW;
+            const std::integral_constant<int, SEMIDETR_GW_NT> nt4;
+            const std::integral_constant<int, kNT5> nt5;
             if constexpr (std::is_same<IO, RawIO>::value) {
                 if (io.has_mask())
-                    window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, true, SEMIDETR_GW_DBG>,
-                                              std::integral_constant<int, SEMIDETR_GW_NT>());
+                    window_gather = L == 4
+                        ? launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, true, SEMIDETR_GW_DBG>, nt4, wl4, px4)
+                        : launch_gw(&msda_gw_d32<IO, kNT5, SEMIDETR_GW_RTH5, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 5, true, SEMIDETR_GW_DBG>, nt5, wl5, px5);
             }
             if (!window_gather && !io.has_mask())
-                window_gather = launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false, SEMIDETR_GW_DBG>,
-                                          std::integral_constant<int, SEMIDETR_GW_NT>());
+                window_gather = L == 4
+                    ? launch_gw(&msda_gw_d32<IO, SEMIDETR_GW_NT, SEMIDETR_GW_RTH, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 4, false, SEMIDETR_GW_DBG>, nt4, wl4, px4)
+                    : launch_gw(&msda_gw_d32<IO, kNT5, SEMIDETR_GW_RTH5, SEMIDETR_GW_RTW, SEMIDETR_GW_H0, SEMIDETR_GW_HC, 5, false, SEMIDETR_GW_DBG>, nt5, wl5, px5);
         }
         if (window_gather) {
         } else if (L * P == 16)             // DINO: sample loop unrolled, results in registers

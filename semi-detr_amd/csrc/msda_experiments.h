@@ -25,7 +25,7 @@ int launch_rw(hipStream_t st, const float *grad_out, const float *value, const i
     constexpr size_t lds = rw_lds_bytes<NT, RTH, RTW, H0, HC, KL, TUNE>();
     static_assert(lds <= 160 * 1024, "region-window configuration does not fit the LDS");
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, grad_out, value, spatial_shapes, level_start, io, S, M,
-                       bound, out, zero, zero_n4, FwdStats{nullptr, nullptr, nullptr, nullptr}, 0);
+                       bound, out, zero, zero_n4, FwdStats{nullptr, 0u}, 0);
     return semidetr::launch_status(GATHER ? "msda_rw_d32<gather>" : "msda_rw_d32<forward>");
 }
 

@@ -554,25 +554,35 @@ __device__ __forceinline__ int patch_query(const Patch &p, int r)      // r-th q
 // when it gets there.  All pointers null: nothing is counted (fixed policy, stream capture, allocation failure).
 // ---------------------------------------------------------------------------------------------
 constexpr float kFarPx = 4.0f;
+// ONE pointer and the launch's parity (round 6; it was four pointers: eight scalar registers held from the kernels' first instruction to their last, spilled at once by the
+// fused-prologue instantiations): the call site's 16-word block in device memory --
+//   words [0..3] / [4..7]  {far, total, kind, -} of even / odd launches: this launch accumulates into its parity's four, the other
+//                          four are what the previous launch accumulated: published, then cleared
+//   word  [8]              number of publications so far
+//   words [10..11]         pointer to the slot's record in mapped host memory {sequence, far, total, kind} (written once by the host)
 struct FwdStats {
-    unsigned *cur;      // {far, total, kind, -} this launch accumulates into
-    unsigned *prev;     // the words the previous launch accumulated: published, then cleared
-    unsigned *pub;      // mapped host memory: {sequence, far, total, kind}
-    unsigned *seq;      // device word: number of publications so far
+    unsigned *blk;      // the slot's block (null: nothing is counted)
+    unsigned parity;    // 0 / 1: which four words this launch accumulates into
+    __device__ __forceinline__ bool on() const { return blk != nullptr; }
+    __device__ __forceinline__ unsigned *base() const { return blk; }
+    __device__ __forceinline__ unsigned *cur() const { return blk + 4 * parity; }
+    __device__ __forceinline__ unsigned *prev() const { return blk + 4 * (1u - parity); }
 };
 __device__ __forceinline__ void fwd_stats_publish(const FwdStats &fs)
 {
-    const unsigned far = fs.prev[0], total = fs.prev[1], kind = fs.prev[2];
+    unsigned *const prev = fs.prev(), *const seq = fs.base() + 8;
+    const unsigned far = prev[0], total = prev[1], kind = prev[2];
     if (total) {
         // ONE 16-byte store, no fence: a system-scope release here writes back and invalidates this XCD's whole L2 (measured:
         // +10-15 us on a 270 us launch); the store reaches the host at the latest when this kernel ends, which is early enough
         // for a dispatcher that only ever looks at finished launches.  The host takes a record whose sequence number is new.
-        const unsigned sq = fs.seq[0] + 1u;
-        fs.seq[0] = sq;
-        *reinterpret_cast<uint4 *>(fs.pub) = make_uint4(sq, far, total, kind);
+        const unsigned sq = seq[0] + 1u;
+        seq[0] = sq;
+        unsigned *const pub = *reinterpret_cast<unsigned *const *>(fs.base() + 10);
+        *reinterpret_cast<uint4 *>(pub) = make_uint4(sq, far, total, kind);
     }
-    fs.prev[0] = 0u;
-    fs.prev[1] = 0u;
+    prev[0] = 0u;
+    prev[1] = 0u;
 }
 // one wave's counts -> the launch's counter pair
 __device__ __forceinline__ void fwd_stats_add(const FwdStats &fs, unsigned far, unsigned total, unsigned kind)
@@ -585,9 +595,10 @@ __device__ __forceinline__ void fwd_stats_add(const FwdStats &fs, unsigned far, 
     // (lane number from the exec mask, not from threadIdx: the thread index would stay in a register from the kernel's first
     //  instruction to this one -- in the five-level region-window kernel that was one of three spilled registers)
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0 && total) {
-        atomicAdd(fs.cur, far);
-        atomicAdd(fs.cur + 1, total);
-        fs.cur[2] = kind;
+        unsigned *const cur = fs.cur();
+        atomicAdd(cur, far);
+        atomicAdd(cur + 1, total);
+        cur[2] = kind;
     }
 }
 
@@ -596,7 +607,7 @@ template <int SPLIT, int UNROLL, int PATCH = 0, typename IO = LocAttnIO>
 __global__ __launch_bounds__(256) void msda_fwd_d32(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ starts,
     const IO io, int S, int M, int L, int Lq, int P, int tiles_per_image, float *__restrict__ out,
-    const FwdStats fs = FwdStats{nullptr, nullptr, nullptr, nullptr})
+    const FwdStats fs = FwdStats{nullptr, 0u})
 {
     constexpr int RPB = 32 / SPLIT;   // query rows per workgroup
     extern __shared__ float4 smem[];
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
     Patch pt = {0, 0, 0, 0, 0};
     bool sampled = false;                 // this workgroup counts how far its samples reach (FwdStats)
     if constexpr (PATCH != 0) {
-        if (fs.cur) {
+        if (fs.on()) {
             sampled = (blockIdx.x & 255) == 1;
         }
     }
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(256) void msda_fwd_d32(
         if (pt.Hq == 0) {
             // the launch's FIRST workgroup hands the previous launch's counts to the host when it is done: it started first,
             // so this is nowhere near the launch's tail (at its start the few dependent loads delayed its CU's whole queue)
-            if (fs.cur && blockIdx.x == 0 && threadIdx.x == 0) fwd_stats_publish(fs);
+            if (fs.on() && blockIdx.x == 0 && threadIdx.x == 0) fwd_stats_publish(fs);
             return;
         }
         __syncthreads();      // previous patch done with the LDS records

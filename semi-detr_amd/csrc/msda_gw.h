@@ -1,5 +1,6 @@
 // Gather half of the encoder self-attention BACKWARD with ONE LANE PER SAMPLE on region windows in LDS (fp32, D == 32,
-// num_point == 4, four levels: L * P == 16 samples per (query, head) = one DPP row): grad_sampling_loc / grad_attn_weight
+// num_point == 4; four levels: L * P == 16 samples per (query, head) = one DPP row, four rows per wave; five levels (round 6, the
+// COCO-Full pyramid): L * P == 20, three rows of 20 lanes per wave, lanes 60..63 idle): grad_sampling_loc / grad_attn_weight
 // (ms_deform_im2col_cuda.cuh:87-159, :301-403), optionally clearing grad_value for the scatter launch that follows.
 // Included by msda.hip after msda_rw.h (window geometry RwWin, rw_first).  Round 5.
 //
@@ -59,6 +60,30 @@ __device__ __forceinline__ void row16_sum4(float &a, float &b, float &c, float &
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
+// Sum / maximum over a 20-lane row of the five-level layout (rows start at lanes 0, 20, 40: quad-aligned, not DPP-row aligned): two DPP
+// steps inside the quad (= the four points of one level), then the five quad totals of the row through ds_bpermute, added in quad
+// order by every lane -- all lanes of a row get the same bits.  bp = 4 * (row's first lane + my position in my quad).
+__device__ __forceinline__ float gw_row_sum(float x, int bp)
+{
+    x += dpp_mov<0xB1>(x);
+    x += dpp_mov<0x4E>(x);
+    const int xi = __float_as_int(x);
+    const float t0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp, xi)), t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 16, xi));
+    const float t2 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 32, xi)), t3 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 48, xi));
+    const float t4 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 64, xi));
+    return ((t0 + t1) + (t2 + t3)) + t4;
+}
+__device__ __forceinline__ float gw_row_max(float x, int bp)
+{
+    x = fmaxf(x, dpp_mov<0xB1>(x));
+    x = fmaxf(x, dpp_mov<0x4E>(x));
+    const int xi = __float_as_int(x);
+    const float t0 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp, xi)), t1 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 16, xi));
+    const float t2 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 32, xi)), t3 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 48, xi));
+    const float t4 = __int_as_float(__builtin_amdgcn_ds_bpermute(bp + 64, xi));
+    return fmaxf(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)), t4);
+}
+
 template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool MASK = false, int DBG = 0>
 __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -66,8 +91,10 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
 {
     io.same_dims(S, M, KL);
     using Wn = RwWin<RTH, RTW, H0, HC, KL>;
-    constexpr int P = kPT, LP = KL * P, QPR = NT / LP;      // queries per round
-    static_assert(H0 >= 0 && LP == 16, "every level has a window; the 16 samples of a (query, head) row fill one DPP row");
+    // RPW (query, head) rows of LP lanes per wave: 4 x 16 (a row = one DPP row) or 3 x 20 (five levels; the row reductions of the
+    // fused prologue then are two DPP steps inside the level's quad + five ds_bpermute over the row's quads, gw_row_sum / gw_row_max)
+    constexpr int P = kPT, LP = KL * P, RPW = 64 / LP, QPR = (NT / 64) * RPW;      // QPR: queries per round
+    static_assert(H0 >= 0 && (LP == 16 || LP == 20), "every level has a window; 16 or 20 samples per (query, head) row");
     static_assert(gw_lds_bytes<NT, RTH, RTW, H0, HC, KL>() <= 160 * 1024, "windows do not fit the LDS");
     constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
 
@@ -85,7 +112,13 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
         return wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
     };
     const int tid = fresh_tid(), lane = tid & 63;
-    const int k = tid & (LP - 1), lvl = k / P;            // my sample of the row, its level
+    // my (query, head) row of the wave, my sample of the row, its level (LP == 20: lanes 60..63 own nothing -- they walk along as
+    // sample 0 of a query-less row and store nothing)
+    const int rowi = LP == 16 ? lane >> 4 : lane / LP;
+    const int k = LP == 16 ? (lane & 15) : (rowi < RPW ? lane - rowi * LP : 0), lvl = k / P;
+    // LP == 20: ds_bpermute address of "my position in quad 0 of my row" (the row's quads follow at + 16 bytes each)
+    const int bp_row = (rowi < RPW ? rowi * LP + (lane & 3) : lane) * 4;
+    (void)bp_row;
     const int Lq = S, rs = M * kD;
     const int b = (int)blockIdx.x;
     const int m = (b % M + (b / M) / kRwHeadRun) % M;
@@ -275,7 +308,12 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
         //  the launcher checks Lq * M * L * P * 8 < 2^32 -- instead of 64-bit multiplies by every lane in every round)
         const IO ion = io.image_view(n, Lq, M, LP);
         auto fetch = [&](int round_, Pre &p) {
-            p.q = query_of_slot(round_ * QPR + (fresh_tid() >> 4));
+            if constexpr (LP == 16) {
+                p.q = query_of_slot(round_ * QPR + (fresh_tid() >> 4));
+            } else {
+                const int ln_ = fresh_tid() & 63, rw_ = ln_ / LP;
+                p.q = query_of_slot(rw_ < RPW ? round_ * QPR + wave_s * RPW + rw_ : 0x3fffffff);
+            }
             const unsigned qs_ = p.q >= 0 ? (unsigned)p.q : 0u;       // (a lane without a query reads query 0 of the image and stores nothing)
             const unsigned row_ = qs_ * (unsigned)M + (unsigned)m;
             p.rxy = ion.load_xy_raw(row_, qs_, LP, k, lvl);
@@ -307,7 +345,14 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             float x, y;
             io.finish_xy_raw(cur.rxy, P, myH, myW, x, y);
             const float raw = cur.raw;
-            const float a = row_softmax(ion, row, LP, k, raw);      // fused prologue: over the 16 lanes of my DPP row
+            float a;                                                // fused prologue: softmax over the LP lanes of my row
+            if constexpr (LP == 16 || !IO::kSoftmax) {
+                a = row_softmax(ion, row, LP, k, raw);              // (16: one DPP row)
+            } else {
+                const float mx = gw_row_max(raw, bp_row);
+                const float e = __expf(raw - mx);                   // __expf / v_rcp_f32 as row_softmax
+                a = e * fast_rcp(gw_row_sum(e, bp_row));
+            }
 
             // ---- geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 zero padding)
             const float Hf = (float)myH, Wf = (float)myW;
@@ -376,7 +421,12 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             if (far) {
                 float lw_, lh_;
                 sample_setup_oob(x, y, myH, myW, myst, row_bytes, foff, lw_, lh_);
-                if constexpr (MASK) mask_corners_oob(io, MaskExt{lvl == 0 ? ves[0] : (lvl == 1 ? ves[1] : (lvl == 2 ? ves[2] : ves[KL - 1]))}, n, x, y, myH, myW, myst, foff);
+                if constexpr (MASK) {
+                    int ve_my = ves[0];
+#pragma unroll
+                    for (int l = 1; l < KL; ++l) ve_my = lvl == l ? __builtin_amdgcn_readfirstlane(ves[l]) : ve_my;
+                    mask_corners_oob(io, MaskExt{ve_my}, n, x, y, myH, myW, myst, foff);
+                }
             }
             const unsigned long long fb = DBG == 4 ? 0ull : __ballot(far);
             if (fb) {      // (wave-uniform)
@@ -425,7 +475,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             const float g_x = inside ? a * (hh * (d2 - d1) + lh * (d4 - d3)) : 0.f;
             const float g_y = inside ? a * (b_ - t_) : 0.f;
             float dot = 0.f;                       // fused epilogue: sum_k a_k g_k over the row (softmax backward)
-            if (IO::kSoftmax) dot = lp_group_sum(a * g_a, 16);
+            if (IO::kSoftmax) dot = LP == 16 ? lp_group_sum(a * g_a, 16) : gw_row_sum(a * g_a, bp_row);
             if (act) ion.store_with_dot(row, nq, LP, k, lvl, P, myH, myW, make_float4(g_a, g_x * Wf, g_y * Hf, a), dot);
         }
     }

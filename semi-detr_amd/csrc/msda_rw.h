@@ -177,7 +177,7 @@ template <typename IO, int NT, int RTH, int RTW, int H0, int HC, int KL, bool GA
 __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(      // 256-thread workgroups: two per CU
     const float *__restrict__ gout, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ starts, const IO io, int S, int M, int regions_bound, float *__restrict__ out,
-    float4 *__restrict__ zero, int64_t zero_n4, const FwdStats fs = FwdStats{nullptr, nullptr, nullptr, nullptr}, int tail_cus = 0)
+    float4 *__restrict__ zero, int64_t zero_n4, const FwdStats fs = FwdStats{nullptr, 0u}, int tail_cus = 0)
 {
     io.same_dims(S, M, KL);
     using Wn = RwWin<RTH, RTW, H0, HC, KL>;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     // how far the samples reach, for the dispatcher's choice between this kernel and the patch kernel (FwdStats, msda_fast.h):
     // one workgroup in 128 counts (its first round: G = NT / 8 queries x 12 samples; ~20 workgroups of a bs-4 launch), the launch's first
     // workgroup publishes the previous launch's pair
-    const bool sampled = !GATHER && fs.cur != nullptr && (b & 127) == 1 && part == 0;
+    const bool sampled = !GATHER && fs.on() && (b & 127) == 1 && part == 0;
 
     const __amdgpu_buffer_rsrc_t vr = image_rsrc(value + (int64_t)n * S * M * kD, (unsigned)S * M * kD * 4u);
     const unsigned lane_b = (unsigned)(m * kD + 4 * j8) * 4u;
@@ -820,7 +820,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     const int lv = min(k / P, KL - 1);
                     int ve = ves[0];
 #pragma unroll
-                    for (int l = 1; l < KL; ++l) ve = lv == l ? ves[l] : ve;
+                    for (int l = 1; l < KL; ++l) ve = lv == l ? __builtin_amdgcn_readfirstlane(ves[l]) : ve;      // (readfirstlane: a select chain over a
+                                                                                                      //  small array otherwise becomes an indexed SCRATCH array)
                     pme = MaskExt{ve};
                 }
                 if (act && j8 == (k & 7)) {
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         if constexpr (MASK) {      // padded corners read as zero (the level's summary, or its bytes)
                             int ve = ves[0];
 #pragma unroll
-                            for (int l = 1; l < KL; ++l) ve = (k2[i] / P) == l ? ves[l] : ve;
+                            for (int l = 1; l < KL; ++l) ve = (k2[i] / P) == l ? __builtin_amdgcn_readfirstlane(ves[l]) : ve;
                             const int vh = ext_vh(ve), vw = ext_vw(ve);
                             if (vh >= 0) {
                                 const bool py0 = h0 >= vh, py1 = h0 + 1 >= vh, px0 = w0 >= vw, px1 = w0 + 1 >= vw;
@@ -1135,5 +1136,5 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     }
     if (sampled) fwd_stats_add(fs, st_far, st_total, 2u);
     // the launch's first workgroup hands the previous launch's counts to the host when it is done (see msda_fwd_d32)
-    if (!GATHER && fs.cur != nullptr && b == 0 && tid == 0) fwd_stats_publish(fs);
+    if (!GATHER && fs.on() && b == 0 && tid == 0) fwd_stats_publish(fs);
 }

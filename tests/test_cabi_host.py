@@ -39,25 +39,29 @@ def test_library_exports_every_declared_symbol():
     assert exp.semidetr_abi_version() == 6
 
 
-def _kernel_metadata_counts(blob, key):
-    """values of an integer key of the kernels' msgpack metadata (key, then a fixint / uint8 / uint16 / uint32)"""
-    out, at = [], 0
+def _code_object_kernels(path):
+    """the AMDGPU code objects' kernel metadata of a host library: {demangled kernel name: metadata map} (msgpack notes,
+    `amdhsa.kernels`; one note per translation unit)"""
+    import subprocess
+
+    import msgpack
+    blob = open(path, "rb").read()
+    out, at = {}, 0
     while True:
-        at = blob.find(key, at)
+        at = blob.find(b"\xaeamdhsa.kernels", at)
         if at < 0:
-            return out
-        p = at + len(key)
-        v = blob[p]
-        if v == 0xcc:
-            v = blob[p + 1]
-        elif v == 0xcd:
-            v = int.from_bytes(blob[p + 1:p + 3], "big")
-        elif v == 0xce:
-            v = int.from_bytes(blob[p + 1:p + 5], "big")
-        else:
-            assert v < 0x80, hex(v)             # positive fixint
-        out.append(v)
-        at = p
+            break
+        u = msgpack.Unpacker(raw=False, strict_map_key=False)
+        u.feed(blob[at - 1:at - 1 + (8 << 20)])                # the fixmap header precedes the first key
+        for k in next(u)["amdhsa.kernels"]:
+            out[k[".name"]] = k
+        at += 1
+    names = list(out)
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    return {d.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]: out[n] for n, d in zip(names, dem)}
+
+
+SGPR_SPILL_CEILING_LOCATTN, SGPR_SPILL_CEILING_RAW = 53, 98      # measured maxima 45 / 90 (region scatter) + 8
 
 
 def test_product_code_object_holds_only_reachable_msda_kernels():
@@ -73,7 +77,7 @@ def test_product_code_object_holds_only_reachable_msda_kernels():
     syms = subprocess.run(["strings", "-a", os.path.join(csrc, "libsemidetr_hip.so")], capture_output=True, text=True).stdout
     kernels = set(re.findall(r"_ZN12_GLOBAL__N_1\d+(msda_[a-z0-9_]+)I[^\n]*?\.kd", syms))
     names = set(re.findall(r"(_ZN12_GLOBAL__N_1\d+msda_[A-Za-z0-9_]+)\.kd", syms))
-    assert 20 <= len(names) <= 40, sorted(names)
+    assert 20 <= len(names) <= 48, sorted(names)      # (round 6: + the five-level window gather x 3)
     for banned in ("msda_bwd_dest_d32", "msda_fwd_d32_lw", "msda_fwd_d32_res", "msda_bwd_enc_merged", "msda_bwd_encreg_merged",
                    "msda_bwd_lvl_coop", "msda_bwd_scatter_d32_win", "stream_kernel", "msda_bwd_own_merged",
                    "msda_fwd_d32_ws", "msda_bwd_lvl_mergedI", "msda_bwd_enc_fused_d32"):
@@ -83,15 +87,22 @@ def test_product_code_object_holds_only_reachable_msda_kernels():
     # (round 5: the four-level configuration twice -- with and without the tail split of small launches, msda_rw.h TUNE + 102400)
     assert len(rw) == 9 and sum("Li768ELi25ELi16ELin1ELi5ELi4ELb0E" in n for n in rw) == 6 and \
         sum("Li960ELi24ELi16ELin1ELi4ELi5ELb0E" in n for n in rw) == 3 and sum("ELb1EEEvPKf" in n for n in rw) == 3, rw      # (... MASK = true> of the fused prologue)
-    # No kernel of the product spills VECTOR registers (scratch is per-lane memory on gfx950: a handful of spilled registers cost
-    # the window forward 30 % and hid the whole gain of the scatter's third workgroup per CU -- DESIGN.md section 6).  SCALAR
-    # registers do get spilled by the fused-prologue kernels (their argument block alone is ~40 of them): those go into lanes of
-    # a vector register the kernel then holds (v_writelane / v_readlane, no memory), 64 per register -- counted in the kernel's
-    # VGPR number, so the occupancy the design states already includes them.  Ceiling: two such registers.
-    blob = open(os.path.join(csrc, "libsemidetr_hip.so"), "rb").read()
-    vspills, sspills = _kernel_metadata_counts(blob, b".vgpr_spill_count"), _kernel_metadata_counts(blob, b".sgpr_spill_count")
-    assert len(vspills) >= 40 and max(vspills) == 0, vspills
-    assert len(sspills) == len(vspills) and max(sspills) <= 128, sspills
+    # No kernel of the product spills VECTOR registers or uses SCRATCH (per-lane memory on gfx950: a handful of spilled registers
+    # cost the window forward 30 % and hid the whole gain of the scatter's third workgroup per CU -- DESIGN.md section 6; a kernel can
+    # also reach scratch with zero VGPR spills, when spilled SCALAR registers find no free lane: VERDICT r05, the five-level masked
+    # window forward).  SCALAR registers spilled into lanes of a vector register the kernel holds (v_writelane / v_readlane, no
+    # memory) are tolerated up to a ceiling per IO policy = the largest count measured when the ceiling was written + 8, so that a
+    # change which makes them worse fails here with the kernel's NAME.
+    meta = _code_object_kernels(os.path.join(csrc, "libsemidetr_hip.so"))
+    msda = {n: k for n, k in meta.items() if n.startswith("msda_")}
+    assert len(msda) >= 40, sorted(msda)
+    bad = {n: (k[".vgpr_spill_count"], k[".private_segment_fixed_size"]) for n, k in meta.items()
+           if k[".vgpr_spill_count"] or k[".private_segment_fixed_size"]}
+    assert not bad, "VGPR spills / scratch: %r" % bad
+    ceilings = {"LocAttnIO": SGPR_SPILL_CEILING_LOCATTN, "RawIO": SGPR_SPILL_CEILING_RAW}
+    over = {n: k[".sgpr_spill_count"] for n, k in msda.items()
+            if k[".sgpr_spill_count"] > next((c for io, c in ceilings.items() if io in n), 0)}
+    assert not over, "SGPR spills above the policy's ceiling: %r" % over
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", os.path.join(csrc, "libsemidetr_hip.so")],
                                           capture_output=True, text=True).stdout
     assert kernels >= {"msda_fwd_d32", "msda_rw_d32", "msda_bwd_gather_d32", "msda_bwd_scatter_d32_reg", "msda_bwd_lvl_merged_wide",

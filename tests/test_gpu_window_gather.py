@@ -38,6 +38,11 @@ def _fused_expect(shp, loc, attn, o_gl, o_ga):
     ([(20, 27), (10, 14), (5, 7), (3, 4)], 3, "far"),           # samples anywhere: (almost) every sample leaves its window
     ([(37, 53), (19, 27), (10, 14), (5, 7)], 2, "wide"),        # ragged regions, samples partly outside the map
     ([(16, 16), (16, 16), (15, 17), (2, 2)], 2, "near"),        # not a halving pyramid: any input is correct
+    # five levels (round 6, the COCO-Full pyramid: 20 lanes per (query, head) row, three rows per wave, up-to-13 x 16 regions)
+    ([(37, 53), (19, 27), (10, 14), (5, 7), (3, 4)], 2, "near"),
+    ([(37, 53), (19, 27), (10, 14), (5, 7), (3, 4)], 2, "wide"),
+    ([(20, 27), (10, 14), (5, 7), (3, 4), (2, 2)], 3, "far"),
+    ([(16, 16), (16, 16), (15, 17), (2, 2), (1, 1)], 2, "near"),
 ])
 def test_window_gather_reference_contract_vs_oracle(shapes, N, mode):
     import MultiScaleDeformableAttention as MSDA
@@ -52,7 +57,8 @@ def test_window_gather_reference_contract_vs_oracle(shapes, N, mode):
     np.testing.assert_allclose(gv.cpu().numpy(), o_gv, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gv).max())))
 
 
-@pytest.mark.parametrize("shapes", [[(37, 53), (19, 27), (10, 14), (5, 7)], [(16, 16), (16, 16), (15, 17), (2, 2)]], ids=["pyramid", "no_pyramid"])
+@pytest.mark.parametrize("shapes", [[(37, 53), (19, 27), (10, 14), (5, 7)], [(16, 16), (16, 16), (15, 17), (2, 2)],
+                                    [(37, 53), (19, 27), (10, 14), (5, 7), (3, 4)]], ids=["pyramid", "no_pyramid", "five_levels"])
 @pytest.mark.parametrize("kind", [None, "band", "band_with_holes", "random"])
 @pytest.mark.parametrize("sigma", [2.0, 9.0, 40.0], ids=["near", "past_the_windows", "anywhere"])
 def test_window_gather_fused_prologue_and_mask_vs_oracle(shapes, kind, sigma):
@@ -68,7 +74,7 @@ def test_window_gather_fused_prologue_and_mask_vs_oracle(shapes, kind, sigma):
         if kind == "band_with_holes":
             st = np.concatenate([[0], np.cumsum(shp[:, 0] * shp[:, 1])])
             mask[1, st[1] + 3] = True
-            mask[1, st[4] - 1] = False
+            mask[1, st[len(shapes)] - 1] = False
         elif kind == "random":
             mask = np.random.default_rng(17).random((N, S)) < 0.15
     loc, attn = _prologue_np(ref, off, logits, shp, P)
@@ -93,11 +99,13 @@ def test_window_gather_fused_prologue_and_mask_vs_oracle(shapes, kind, sigma):
     np.testing.assert_allclose(gv, o_gv, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gv).max())))
 
 
+@pytest.mark.parametrize("levels", [LEVELS, LEVELS + [(7, 11)]], ids=["four_levels", "five_levels"])
 @pytest.mark.parametrize("io", ["locattn", "raw", "raw_masked"])
-def test_window_gather_full_size_vs_oracle(io):
-    """N = 4, Lq = S = 22 223, sigma 2 px (the launch bench.py times): every element of the two small gradients."""
+def test_window_gather_full_size_vs_oracle(io, levels):
+    """N = 4, Lq = S = 22 223 (22 300 with the COCO-Full recipe's fifth level), sigma 2 px (the launches bench.py times): every
+    element of the two small gradients."""
     import MultiScaleDeformableAttention as MSDA
-    value, shp, ref, off, logits, gout = _encoder_case(4, LEVELS, 2.0, 29)
+    value, shp, ref, off, logits, gout = _encoder_case(4, levels, 2.0, 29)
     mask = _band_mask(shp, [(1.0, 1.0), (0.85, 0.6), (0.6, 1.0), (0.75, 0.75)]) if io == "raw_masked" else None
     loc, attn = _prologue_np(ref, off, logits, shp, P)
     vm = value.copy()

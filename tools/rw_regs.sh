@@ -8,4 +8,4 @@ N=$(grep -n '#include "msda_rw.h"' semi-detr_amd/csrc/msda.hip | head -1 | cut -
 { sed -n "1,${N}p" semi-detr_amd/csrc/msda.hip | grep -v "msda_fast_experiments.h"; echo "}"; echo "void *force_it() { return (void *)&$K<$1>; }"; } > /tmp/asm/rwtest.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Iinclude -Isemi-detr_amd/csrc -Wno-pass-failed -Wno-unused-variable -Wno-unused-function \
   --offload-device-only -S /tmp/asm/rwtest.hip -o /tmp/asm/rwtest.s 2>&1 | grep "error" | head -20
-grep "vgpr_count\|vgpr_spill\|sgpr_count" /tmp/asm/rwtest.s | tr -s ' ' | tr '\n' ' '; echo
+grep "vgpr_count\|vgpr_spill\|sgpr_count\|sgpr_spill\|private_segment_fixed" /tmp/asm/rwtest.s | tr -s ' ' | tr '\n' ' '; echo
