@@ -96,7 +96,7 @@ constexpr int kMaxLevels = 32;
 #endif
 #ifndef SEMIDETR_GW_NT           // msda_gw_d32 (lane-per-sample gather of the encoder backward): threads, region, margins of level 0 / the coarse levels
 #define SEMIDETR_GW_NT 1024      // (round 5, second half: 768 -> 1024 once nothing spilled there)
-#define SEMIDETR_GW_RTH 16
+#define SEMIDETR_GW_RTH 15      // (round 6: 15, not 16 -- the grad_out rows of a round need 8 KB of LDS beside the windows; a 100-row level is 7 x 14.3 rows either way)
 #define SEMIDETR_GW_RTW 16
 #define SEMIDETR_GW_H0 4
 #define SEMIDETR_GW_HC 4
@@ -104,7 +104,7 @@ constexpr int kMaxLevels = 32;
 #ifndef SEMIDETR_GW_RTH5
 #define SEMIDETR_GW_RTH5 13      // ... five levels: the windows of all five at margin 4 fit beside the query list with regions of up to 13 x 16 pixels
 #define SEMIDETR_GW_NT5 1024     //     (a 100-row level = 8 x 12.5 rows; 14 rows -- the same tiling -- would need 165 KB)
-#define SEMIDETR_GW_NT5_RAW 768  //     the fused prologue's five-level instantiations spill 4 / 9 vector registers at 1024 threads (128 VGPRs)
+#define SEMIDETR_GW_NT5_RAW 1024 //     (with the grad_out rows in LDS the fused prologue fits 1024 threads too: 117 / 128 VGPRs, no spill)
 #endif
 #ifndef SEMIDETR_GW_FB
 #define SEMIDETR_GW_FB 4         // msda_gw_d32: far samples whose loads are in flight together
@@ -258,6 +258,10 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
 {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float2 buf_ld2(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
 }
 __device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {

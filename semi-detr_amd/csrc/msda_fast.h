@@ -99,6 +99,30 @@ struct LocAttnIO {
         x = r.xy.x;
         y = r.xy.y;
     }
+    // round 6, the window kernels' form (see RawIO): what the loads return; (x, y) from it and the level's reciprocals (unused here)
+    struct RawXYc { float2 xy; };
+    template <typename R>
+    __device__ __forceinline__ RawXYc load_xy_c(R row, R nq, int LP, int k, int l) const
+    {
+        (void)nq; (void)l;
+        return RawXYc{ld_stream2(loc + (row * LP + k) * 2)};
+    }
+    template <typename R>
+    __device__ __forceinline__ void finish_xy_c(const RawXYc &r, R nq, int l, int P, float invW, float invH, float &x, float &y) const
+    {
+        (void)nq; (void)l; (void)P; (void)invW; (void)invH;
+        x = r.xy.x;
+        y = r.xy.y;
+    }
+    // g_x, g_y = d/d (pixel x, pixel y) of the sample; the reference contract returns d/d (normalised location) = that x (W, H)
+    template <typename R>
+    __device__ __forceinline__ void store_px(R row, R nq, int LP, int k, int l, int P, float Hf, float Wf, float g_a, float g_x,
+                                             float g_y, float a, float dot) const
+    {
+        (void)nq; (void)l; (void)P; (void)a; (void)dot;
+        st_stream1(gattn + row * LP + k, g_a);
+        st_stream2(gloc + (row * LP + k) * 2, make_float2(g_x * Wf, g_y * Hf));
+    }
     template <typename R>
     __device__ __forceinline__ float load_w(R row, int LP, int k) const { return ld_stream1(attn + row * LP + k); }
     // res = {d/d attn, d/d loc.x, d/d loc.y, attn} of sample k; row_res = the LP results of the same (n,q,m) row
@@ -212,6 +236,46 @@ struct RawIO {
         const float sx = box ? ip * r.z : fast_rcp((float)W), sy = box ? ip * r.w : fast_rcp((float)H);
         x = r.x + o.x * sx;
         y = r.y + o.y * sy;
+    }
+    // Round 6, the window kernels' form.  Their queries are pixels, whose reference points are 2-d in every DETR encoder
+    // (transformer.py:675-691): the prefetched data is the offset and the 8-byte point -- not the 16-byte box, two registers per
+    // sample held a round ahead -- and 1 / W, 1 / H come from the caller's per-level table (v_rcp_f32 of the float sizes, worked out
+    // once per launch instead of by every lane in every round: a transcendental costs four plain instructions).  A box (ref_dim 4)
+    // fetches its (w, h) where it is used: a dependent load, correct and slow, never taken by the reference's call sites.  Same
+    // bits as finish_xy for both layouts.
+    struct RawXYc { float2 o; float2 c; };
+    template <typename R>
+    __device__ __forceinline__ RawXYc load_xy_c(R row, R nq, int LP, int k, int l) const
+    {
+        return RawXYc{ld_stream2(off + (row * LP + k) * 2), buf_ld2(image_rsrc(ref, ref_bytes), (unsigned)((nq * L + l) * ref_dim) * 4u)};
+    }
+    template <typename R>
+    __device__ __forceinline__ void finish_xy_c(const RawXYc &r, R nq, int l, int P, float invW, float invH, float &x, float &y) const
+    {
+        float sx = invW, sy = invH;
+        if (ref_dim == 4) {      // (wave-uniform)
+            const float2 wh = *reinterpret_cast<const float2 *>(ref + (nq * L + l) * ref_dim + 2);
+            const float ip = 0.5f * fast_rcp((float)P);
+            sx = ip * wh.x;
+            sy = ip * wh.y;
+        }
+        x = r.c.x + r.o.x * sx;
+        y = r.c.y + r.o.y * sy;
+    }
+    // g_x, g_y = d/d (pixel x, pixel y) of the sample.  Points: offsets are in pixels of the level (ms_deform_attn.py:102-105), so the
+    // offset gradient IS the pixel gradient -- no x W / W round trip (store_with_dot multiplies by W and by v_rcp_f32(W))
+    template <typename R>
+    __device__ __forceinline__ void store_px(R row, R nq, int LP, int k, int l, int P, float Hf, float Wf, float g_a, float g_x,
+                                             float g_y, float a, float dot) const
+    {
+        st_stream1(glogit + row * LP + k, a * (g_a - dot));      // softmax backward: a_k * (g_k - sum_j a_j g_j)
+        float2 g = make_float2(g_x, g_y);
+        if (ref_dim != 2) {
+            const float2 wh = *reinterpret_cast<const float2 *>(ref + (nq * L + l) * ref_dim + 2);
+            const float ip = 0.5f * fast_rcp((float)P);
+            g = make_float2(g_x * Wf * wh.x * ip, g_y * Hf * wh.y * ip);
+        }
+        st_stream2(goff + (row * LP + k) * 2, g);
     }
     template <typename R>
     __device__ __forceinline__ float load_w(R row, int LP, int k) const { return ld_stream1(logit + row * LP + k); }

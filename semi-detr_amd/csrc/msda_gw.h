@@ -27,12 +27,19 @@
 //     patch gather when the slot's forward policy says the samples are far, msda.hip).
 #pragma once
 
-constexpr int kGwQList = 1024;      // queries of a region kept as a list in LDS (a region of a halving pyramid has ~340; larger ones compute them)
-constexpr int kGwFarCap = 8;        // far samples a wave hands to its rows at a time (32-byte entries in LDS)
+#ifndef SEMIDETR_GW_SB
+#define SEMIDETR_GW_SB 1            // dot-loop steps (five ds_read_b128 each) between scheduling barriers
+#endif
+constexpr int kGwQList = 512;       // queries of a region kept as a list in LDS (a region of a halving pyramid has ~340; larger ones compute them)
+// far samples a wave hands to its rows at a time (32-byte entries in LDS; four rows take one entry each per trip: five levels, whose windows
+// leave less room, hand over one trip's worth)
+constexpr int gw_far_cap(int KL) { return KL >= 5 ? 4 : 8; }
 template <int NT, int RTH, int RTW, int H0, int HC, int KL>
 constexpr size_t gw_lds_bytes()
 {
-    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)kGwQList * 4 + (size_t)(NT / 64) * kGwFarCap * 32;
+    // windows + query list + far-sample entries + level table + (round 6) the grad_out rows of a round: 64 / (KL * 4) rows of 128 bytes per wave
+    return (size_t)RwWin<RTH, RTW, H0, HC, KL>::total * 128 + (size_t)kGwQList * 4 + (size_t)(NT / 64) * gw_far_cap(KL) * 32 + 128 +
+           (size_t)(NT / 64) * (64 / (KL * 4)) * 128;
 }
 
 // four 16-lane (DPP row) sums at once, as sixteen fused v_add_f32_dpp (see group8_sum3): every lane of a row gets its row's totals
@@ -97,11 +104,21 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
     static_assert(H0 >= 0 && (LP == 16 || LP == 20), "every level has a window; 16 or 20 samples per (query, head) row");
     static_assert(gw_lds_bytes<NT, RTH, RTW, H0, HC, KL>() <= 160 * 1024, "windows do not fit the LDS");
     constexpr unsigned kZ0 = (unsigned)Wn::zrow * 128u;
+    constexpr int kGwFarCap = gw_far_cap(KL);
 
     extern __shared__ __attribute__((aligned(128))) float4 smem[];      // (the chunk swizzle XORs into row addresses)
     char *const lds = reinterpret_cast<char *>(smem);
     int *const qlist = reinterpret_cast<int *>(lds + Wn::total * 128);                                  // the region's queries, in slot order
-    char *const farl = lds + Wn::total * 128 + kGwQList * 4 + (threadIdx.x >> 6) * (kGwFarCap * 32);    // my wave's far-sample entries
+    char *const farl = lds + Wn::total * 128 + kGwQList * 4 + (threadIdx.x >> 6) * (gw_far_cap(KL) * 32);    // my wave's far-sample entries
+    // per level {(float)H, (float)W, 1 / H, 1 / W} (round 6): a lane reads its level's entry once per round instead of converting and
+    // inverting the sizes there (the fused prologue: four v_rcp_f32 per sample -- location arithmetic and offset gradient)
+    float4 *const gtab = reinterpret_cast<float4 *>(lds + Wn::total * 128 + kGwQList * 4 + (NT / 64) * (gw_far_cap(KL) * 32));
+    // the grad_out rows of my wave's (query, head) rows of the current round (round 6): each lane loads ONE 8-byte piece of its query's row
+    // a round ahead and parks it here; the dot loop reads the row's 16-byte chunks from LDS beside the corner rows -- instead of every
+    // lane pulling its query's whole 128-byte row through the vector-memory path into 32 registers (1.46 GB per bs-4 launch for a 91 MB
+    // tensor; SQ_WAIT_ANY was 52 % of the wave cycles).  Only my wave touches its rows: LDS operations of a wave execute in order, no barrier.
+    constexpr unsigned kGstAt = (unsigned)(Wn::total * 128 + kGwQList * 4 + (NT / 64) * (gw_far_cap(KL) * 32) + 128);
+    static_assert(kGstAt % 128 == 0, "the chunk swizzle XORs into the staged rows' addresses");
 
     // the thread index is rebuilt where it is needed from the wave number (a scalar register) and the lane number (two VALU): as a
     // kernel-long vector register it was what the masked instantiation spilled at 1024 threads (the region scatter's trick, msda_region.h)
@@ -137,6 +154,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
 #pragma unroll
     for (int l = 0; l < KL; ++l)
         if (lane == l) { r_wh = Wn::wh(l); r_ww = Wn::ww(l); }
+    if (tid < KL) gtab[tid] = make_float4((float)r_H, (float)r_W, fast_rcp((float)r_H), fast_rcp((float)r_W));      // (read behind the staging barriers)
     int Hs[KL], Ws[KL], sts[KL];
 #pragma unroll
     for (int l = 0; l < KL; ++l) {
@@ -301,8 +319,9 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
         // samples, results and stores and this round's softmax and geometry.
         struct Pre {
             int q;
-            typename IO::RawXY rxy;
+            typename IO::RawXYc rxy;
             float raw;
+            float2 g;      // my 8-byte piece of my query's grad_out row (lane k of the row: piece k & 15)
         };
         // (the sampling data and the results are addressed inside MY image: 32-bit index arithmetic on the image's view of the tensors --
         //  the launcher checks Lq * M * L * P * 8 < 2^32 -- instead of 64-bit multiplies by every lane in every round)
@@ -316,24 +335,12 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             }
             const unsigned qs_ = p.q >= 0 ? (unsigned)p.q : 0u;       // (a lane without a query reads query 0 of the image and stores nothing)
             const unsigned row_ = qs_ * (unsigned)M + (unsigned)m;
-            p.rxy = ion.load_xy_raw(row_, qs_, LP, k, lvl);
+            p.rxy = ion.load_xy_c(row_, qs_, LP, k, lvl);
             p.raw = ion.load_w(row_, LP, k);
-        };
-        float4 go[8];
-        // (my chunk swizzle goes through an empty asm where it is used: the compiler would otherwise keep all its derived offsets --
-        //  8 for the grad_out loads, 8 for the window reads -- in registers for the whole kernel and spill a hundred others)
-        auto fetch_go = [&](int q_, unsigned jr) {
-            const unsigned gbase = (unsigned)((q_ >= 0 ? q_ : 0) * M + m) * 128u + jr;      // (aligned to 128: + is ^)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) go[c] = buf_ld4(gr, gbase ^ ((unsigned)c << 4));
+            p.g = buf_ld2(gr, row_ * 128u + (unsigned)(k & 15) * 8u);      // (LP == 20: lanes 16..19 of a row fetch pieces 0..3 again)
         };
         Pre nxt;
         fetch(0, nxt);
-        {
-            unsigned jr = jj;
-            asm volatile("" : "+v"(jr));
-            fetch_go(nxt.q, jr);
-        }
         for (int round = 0; round < nrounds; ++round) {
             const Pre cur = nxt;
             const int q = cur.q;
@@ -342,8 +349,10 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             const bool act = q >= 0;
             const int qs = act ? q : 0;
             const unsigned nq = (unsigned)qs, row = nq * (unsigned)M + (unsigned)m;      // (inside my image: `ion`)
+            const float4 lt = gtab[lvl];               // my level: (float)H, (float)W, 1 / H, 1 / W
+            const float Hf = lt.x, Wf = lt.y;
             float x, y;
-            io.finish_xy_raw(cur.rxy, P, myH, myW, x, y);
+            ion.finish_xy_c(cur.rxy, nq, lvl, P, lt.w, lt.z, x, y);
             const float raw = cur.raw;
             float a;                                                // fused prologue: softmax over the LP lanes of my row
             if constexpr (LP == 16 || !IO::kSoftmax) {
@@ -355,7 +364,6 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             }
 
             // ---- geometry (ms_deform_im2col_cuda.cuh:285-288 pixel mapping, :56-78 zero padding)
-            const float Hf = (float)myH, Wf = (float)myW;
             const float h = sub_rn(mul_rn(y, Hf), 0.5f), w = sub_rn(mul_rn(x, Wf), 0.5f);
             const bool inside = act && h > -1.f && w > -1.f && h < Hf && w < Wf;
             const float h0f = floorf(h), w0f = floorf(w);
@@ -377,9 +385,14 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             v2f e0 = {0.f, 0.f}, e1 = {0.f, 0.f}, e2 = {0.f, 0.f}, e3 = {0.f, 0.f};
             unsigned jl = jj;
             asm volatile("" : "+v"(jl));
+            // my piece of my query's grad_out row -> my wave's staging rows.  (The idle lanes 60..63 of the five-level layout write nothing
+            // and read row 1: in their ds_read_b128 group sit lanes of rows 1 and 2, and row 1's other half of the chunks is free there.)
+            const unsigned grow = kGstAt + (unsigned)(wave_s * RPW + (rowi < RPW ? rowi : 1)) * 128u;
+            if (rowi < RPW) *reinterpret_cast<float2 *>(lds + grow + (unsigned)(k & 15) * 8u) = cur.g;
             // (rows are 128-byte aligned, and so is the window array: my first chunk of each row, as LDS addresses)
             const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)lds;
             const unsigned b0 = (lds0 + a0) ^ jl, b1 = (lds0 + a1) ^ jl, b2 = (lds0 + a2) ^ jl, b3 = (lds0 + a3) ^ jl;
+            const unsigned bg = (lds0 + grow) ^ jl;      // (my query's staged row, chunks in my swizzle order like the corner rows)
             if (DBG != 3) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -389,7 +402,8 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                 const float4 f1 = *reinterpret_cast<const float4 *>((const char *)(lds_cptr)(uintptr_t)(b1 ^ ((unsigned)c << 4)));
                 const float4 f2 = *reinterpret_cast<const float4 *>((const char *)(lds_cptr)(uintptr_t)(b2 ^ ((unsigned)c << 4)));
                 const float4 f3 = *reinterpret_cast<const float4 *>((const char *)(lds_cptr)(uintptr_t)(b3 ^ ((unsigned)c << 4)));
-                const v2f gl = {go[c].x, go[c].y}, gh = {go[c].z, go[c].w};
+                const float4 gc = *reinterpret_cast<const float4 *>((const char *)(lds_cptr)(uintptr_t)(bg ^ ((unsigned)c << 4)));
+                const v2f gl = {gc.x, gc.y}, gh = {gc.z, gc.w};
                 e0 = __builtin_elementwise_fma(gl, v2f{f0.x, f0.y}, e0);
                 e1 = __builtin_elementwise_fma(gl, v2f{f1.x, f1.y}, e1);
                 e2 = __builtin_elementwise_fma(gl, v2f{f2.x, f2.y}, e2);
@@ -399,17 +413,10 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                 e2 = __builtin_elementwise_fma(gh, v2f{f2.z, f2.w}, e2);
                 e3 = __builtin_elementwise_fma(gh, v2f{f3.z, f3.w}, e3);
                 // two steps' reads in flight (the scheduler would hoist all 32: 128 registers); ONE at 1024 threads (128 registers in all)
-                if ((c & 1) || NT >= 1024) __builtin_amdgcn_sched_barrier(0);
+                if ((c % SEMIDETR_GW_SB) == SEMIDETR_GW_SB - 1) __builtin_amdgcn_sched_barrier(0);
             }
             }
-            // The next round's grad_out rows go into the registers the loop has just released.  ONE empty asm takes the eight partial
-            // sums and hands out the swizzle the loads' addresses are built from: the compiler can neither sink the FMAs below the loads
-            // (it did: two sets of rows live, the window reads spilled to scratch) nor hoist the loads above them.
-            {
-                unsigned jr = jj;
-                asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(jr));
-                if (round + 1 < nrounds) fetch_go(nxt.q, jr);
-            }
+            asm volatile("" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3));      // (the partial sums are final here: nothing of the loop sinks below)
             const float s0 = e0.x + e0.y, s1 = e1.x + e1.y, s2 = e2.x + e2.y, s3 = e3.x + e3.y;
             // reading order -> corner order: top-left, top-right, bottom-left, bottom-right
             float d1 = sw ? s1 : s0, d2 = sw ? s0 : s1, d3 = sw ? s3 : s2, d4 = sw ? s2 : s3;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             const float g_y = inside ? a * (b_ - t_) : 0.f;
             float dot = 0.f;                       // fused epilogue: sum_k a_k g_k over the row (softmax backward)
             if (IO::kSoftmax) dot = LP == 16 ? lp_group_sum(a * g_a, 16) : gw_row_sum(a * g_a, bp_row);
-            if (act) ion.store_with_dot(row, nq, LP, k, lvl, P, myH, myW, make_float4(g_a, g_x * Wf, g_y * Hf, a), dot);
+            if (act) ion.store_px(row, nq, LP, k, lvl, P, Hf, Wf, g_a, g_x, g_y, a, dot);
         }
     }
 }
