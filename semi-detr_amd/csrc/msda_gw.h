@@ -260,7 +260,10 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
 #pragma unroll
                 for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
                     const int py = wy0[l] + wy, px = wx0[l] + wx;
-                    const bool ok = r < rows_ && (unsigned)py < (unsigned)Hs[l] && (unsigned)px < (unsigned)Ws[l];
+                    // (MASK: a summarised level's padded rows -- y >= vh or x >= vw -- are not loaded: the out-of-range offset returns the zeros
+                    //  value.masked_fill(mask, 0) asks for, as in msda_rw_d32)
+                    const int Hv = (MASK && ves[l] >= 0) ? (ves[l] & 0xffff) : Hs[l], Wv = (MASK && ves[l] >= 0) ? (int)((unsigned)ves[l] >> 16) : Ws[l];
+                    const bool ok = r < rows_ && (unsigned)py < (unsigned)Hv && (unsigned)px < (unsigned)Wv;
                     const unsigned goff = ok ? (unsigned)(sts[l] + py * Ws[l] + px) * row_bytes + lane_bs : kOob;
                     if constexpr (MASK) {
                         smk[nst] = 0u;
@@ -279,16 +282,11 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             for (int l = 0; l < KL; ++l) {
                 const int ww_ = Wn::ww(l), rows_ = Wn::rows(l);
                 int r = ocs, wy = ocs / ww_, wx = ocs - wy * ww_;
-                const int vh_l = ves[l] & 0xffff, vw_l = (int)((unsigned)ves[l] >> 16);
-                (void)wy; (void)wx; (void)vh_l; (void)vw_l;
+                (void)wy; (void)wx;
 #pragma unroll
                 for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
-                    if constexpr (MASK) {      // a padded pixel's row is staged as zeros: value.masked_fill(mask, 0)
-                        const bool pad = ves[l] >= 0 ? (wy0[l] + wy >= vh_l || wx0[l] + wx >= vw_l) : smk[ist] != 0;
-                        if (pad) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        wx += RPS % ww_;
-                        wy += RPS / ww_;
-                        if (wx >= ww_) { wx -= ww_; ++wy; }
+                    if constexpr (MASK) {      // a level whose mask is not a summarised band: the bytes loaded beside the rows decide
+                        if (ves[l] < 0 && smk[ist] != 0) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                     if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8s * 16) = sv[ist];
                     ++ist;

@@ -503,7 +503,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
 #pragma unroll
                     for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
                         const int py = wy0[l] + wy, px = wx0[l] + wx;
-                        const bool ok = r < rows_ && (unsigned)py < (unsigned)Hs[l] && (unsigned)px < (unsigned)Ws[l];
+                        // (MASK, round 6: a summarised level's padded rows -- y >= vh or x >= vw, vh <= H, vw <= W -- are not loaded at all:
+                        //  the out-of-range offset returns the zeros value.masked_fill(mask, 0) asks for, and the store phase has nothing to undo)
+                        const int Hv = (MASK && ves[l] >= 0) ? (ves[l] & 0xffff) : Hs[l], Wv = (MASK && ves[l] >= 0) ? (int)((unsigned)ves[l] >> 16) : Ws[l];
+                        const bool ok = r < rows_ && (unsigned)py < (unsigned)Hv && (unsigned)px < (unsigned)Wv;
                         const unsigned goff = ok ? (unsigned)(sts[l] + py * Ws[l] + px) * row_bytes + lane_bs : kOob;
                         // (a level with a summary needs no bytes: wave-uniform branch; a row that is not loaded reads byte 0 and ignores it)
                         if constexpr (MASK) {
@@ -527,16 +530,12 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 for (int l = 0; l < KL; ++l) {
                     const int ww_ = Wn::ww(l), rows_ = Wn::rows(l);
                     int r = ocs, wy = ocs / ww_, wx = ocs - wy * ww_;
-                    const int ve_l = ves[l], vh_l = ext_vh(ve_l), vw_l = ext_vw(ve_l);
-                    (void)wy; (void)wx; (void)vh_l; (void)vw_l;
+                    (void)wy; (void)wx;
 #pragma unroll
                     for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
-                        if constexpr (MASK) {      // a padded pixel's row is staged as zeros: value.masked_fill(mask, 0)
-                            const bool pad = vh_l >= 0 ? (wy0[l] + wy >= vh_l || wx0[l] + wx >= vw_l) : smk[ist] != 0;
-                            if (pad) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            wx += RPS % ww_;
-                            wy += RPS / ww_;
-                            if (wx >= ww_) { wx -= ww_; ++wy; }
+                        if constexpr (MASK) {      // a padded pixel's row is staged as zeros: value.masked_fill(mask, 0).  Summarised levels never
+                            // loaded theirs (above); a level whose mask has another form carries the bytes it loaded beside the rows
+                            if (ves[l] < 0 && smk[ist] != 0) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
                         if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8s * 16) = sv[ist];
                         ++ist;
@@ -553,7 +552,17 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 if (tids < KL) {
                     ltab[tids * 3 + 0] = make_int4(r_H, r_W, r_st, r_row0);
                     ltab[tids * 3 + 1] = make_int4(r_wh - 1, r_ww - 1, r_ww, r_wy0);
-                    ltab[tids * 3 + 2] = make_int4(r_wx0, __float_as_int((float)r_H), __float_as_int((float)r_W), 0);
+                    // .w (round 6): the level's VALID extent, rows | columns << 16 -- the padding mask's summary {vh, vw} (vh <= H, vw <= W:
+                    // a corner is real iff y < vh and x < vw), the level's own size without a mask; bit 31: the mask of this level is not of
+                    // that form, its bytes decide.  Corner validity then costs the masked kernel what it costs the unmasked one.
+                    int valid = r_H | (r_W << 16);
+                    if constexpr (MASK) {
+                        int ve_l = -1;
+#pragma unroll
+                        for (int l = 0; l < KL; ++l) ve_l = tids == l ? __builtin_amdgcn_readfirstlane(ves[l]) : ve_l;
+                        valid = ve_l >= 0 ? ve_l : (valid | (int)0x80000000);
+                    }
+                    ltab[tids * 3 + 2] = make_int4(r_wx0, __float_as_int((float)r_H), __float_as_int((float)r_W), valid);
                 }
             }
             if constexpr (kQList) {    // (every lane runs slot_query: its shuffles read lanes 0 .. KL-1)
@@ -687,20 +696,27 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 if (fine && k < P) {
                     // {4 corner byte offsets (kOob: outside the level / no sample), 4 weights}: the plain kernel's record
                     const int h0 = (int)h0f, w0 = (int)w0f;
-                    const bool top = h0 >= 0, bot = h0 + 1 <= c.H - 1, lef = w0 >= 0, rig = w0 + 1 <= c.W - 1;
+                    bool top = h0 >= 0, bot = h0 + 1 <= c.H - 1, lef = w0 >= 0, rig = w0 + 1 <= c.W - 1;
+                    if constexpr (MASK && kTab) {      // (rows / columns of the level that are real: four unsigned compares, mask or no mask)
+                        const unsigned Hv = (unsigned)T2[p].w & 0x7fffu, Wv = ((unsigned)T2[p].w >> 16) & 0x7fffu;
+                        top = (unsigned)h0 < Hv; bot = (unsigned)(h0 + 1) < Hv; lef = (unsigned)w0 < Wv; rig = (unsigned)(w0 + 1) < Wv;
+                    }
                     const unsigned base = (unsigned)(c.st + h0 * c.W + w0) * row_bytes;      // may wrap for -1: unused then
                     const unsigned wrow = (unsigned)c.W * row_bytes;
                     bool c_tl = inside && top && lef, c_tr = inside && top && rig, c_bl = inside && bot && lef, c_br = inside && bot && rig;
                     if constexpr (MASK) {
                         // padded corners read as zero.  With the level's summary: two compares per corner; without: its bytes
-                        const int ve0 = ves[0], vh0 = ext_vh(ve0), vw0 = ext_vw(ve0);
+                        // (kTab: the summary already is the valid extent above; bit 31 of the table word = this level's bytes decide)
+                        const int ve0 = kTab ? 0 : ves[0], vh0 = kTab ? -1 : ext_vh(ve0), vw0 = kTab ? -1 : ext_vw(ve0);
+                        bool bytes = inside;
+                        if constexpr (kTab) bytes = inside && T2[p].w < 0;
                         if (vh0 >= 0) {
                             const bool py0 = h0 >= vh0, py1 = h0 + 1 >= vh0, px0 = w0 >= vw0, px1 = w0 + 1 >= vw0;
                             c_tl = c_tl && !(py0 || px0);
                             c_tr = c_tr && !(py0 || px1);
                             c_bl = c_bl && !(py1 || px0);
                             c_br = c_br && !(py1 || px1);
-                        } else if (inside) {
+                        } else if (bytes) {
                             const unsigned char *gp = mask_of_image() + (c.st + h0 * c.W + w0);
                             c_tl = c_tl && !gp[0];      // (evaluated left to right: a corner outside the level is never dereferenced)
                             c_tr = c_tr && !gp[1];
@@ -1028,27 +1044,22 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         gmask &= gmask - 1;
                         g2[i] = *reinterpret_cast<const float4 *>(orec + (k2[i] - kRec0) * 16);
                         tl[i] = ltab[(k2[i] / P) * 3];
+                        if constexpr (MASK) tl[i].w = ltab[(k2[i] / P) * 3 + 2].w;      // (the level's valid extent, see the table)
                     }
 #pragma unroll
                     for (int i = 0; i < kTrip; ++i) {
                         const int pk = __float_as_int(g2[i].w);
                         const int h0 = (pk & 0x7fff) - 1, w0 = ((pk >> 15) & 0x7fff) - 1, H_ = tl[i].x, W_ = tl[i].y;
                         const bool ok = act2[i] && !(pk >> 30);
-                        const bool top = h0 >= 0, bot = h0 + 1 <= H_ - 1, lef = w0 >= 0, rig = w0 + 1 <= W_ - 1;
+                        bool top = h0 >= 0, bot = h0 + 1 <= H_ - 1, lef = w0 >= 0, rig = w0 + 1 <= W_ - 1;
+                        if constexpr (MASK) {
+                            const unsigned Hv = (unsigned)tl[i].w & 0x7fffu, Wv = ((unsigned)tl[i].w >> 16) & 0x7fffu;
+                            top = (unsigned)h0 < Hv; bot = (unsigned)(h0 + 1) < Hv; lef = (unsigned)w0 < Wv; rig = (unsigned)(w0 + 1) < Wv;
+                        }
                         bool c_tl = ok && top && lef, c_tr = ok && top && rig, c_bl = ok && bot && lef, c_br = ok && bot && rig;
                         const int pix = tl[i].z + h0 * W_ + w0;
-                        if constexpr (MASK) {      // padded corners read as zero (the level's summary, or its bytes)
-                            int ve = ves[0];
-#pragma unroll
-                            for (int l = 1; l < KL; ++l) ve = (k2[i] / P) == l ? __builtin_amdgcn_readfirstlane(ves[l]) : ve;
-                            const int vh = ext_vh(ve), vw = ext_vw(ve);
-                            if (vh >= 0) {
-                                const bool py0 = h0 >= vh, py1 = h0 + 1 >= vh, px0 = w0 >= vw, px1 = w0 + 1 >= vw;
-                                c_tl = c_tl && !(py0 || px0);
-                                c_tr = c_tr && !(py0 || px1);
-                                c_bl = c_bl && !(py1 || px0);
-                                c_br = c_br && !(py1 || px1);
-                            } else {
+                        if constexpr (MASK) {      // padded corners read as zero: the valid extent above, or (bit 31) the level's bytes
+                            if (tl[i].w < 0 && ok) {
                                 const unsigned char *gp = mask_of_image() + pix;
                                 c_tl = c_tl && !gp[0];      // (left to right: a corner outside the level is never dereferenced)
                                 c_tr = c_tr && !gp[1];
