@@ -828,26 +828,39 @@ def cpu_baseline(wl=None):
             "min_max_s": spread}
 
 
-def forward_policy_bench(dev, iters=24, nsets=4):
+def forward_policy_bench(dev, iters=24, nsets=4, levels=None, sigmas=(1.0, 2.0, 4.0, 6.0)):
     """Encoder self-attention forward at bs 4 (the step's dominant launch) by how far the samples reach: sigma = 1 / 2 / 4 / 6 px of
-    the sampled level (the kernels are level at ~5.5 px), rotated input sets, under the three policies of semidetr_msda_set_forward_policy.  `adaptive` is
+    the sampled level (the kernels are level at ~5.5 px) and the reference's own initial offset STAR (`star`, `star_x2`), rotated input sets, forward and
+    backward, under the three policies of semidetr_msda_set_forward_policy.  `adaptive` is
     timed after the dispatcher has seen the data (a few synchronised launches); it must sit on the faster kernel's time."""
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd as sda
+    LEVELS = levels or globals()["LEVELS"]      # noqa: N806 (the four-level pyramid unless the caller names another)
+    L, S = len(LEVELS), sum(h * w for h, w in LEVELS)      # noqa: N806
     shapes = torch.as_tensor(LEVELS, dtype=torch.long, device=dev)
     starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
     ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h, (torch.arange(w, device=dev) + 0.5) / w,
                                                 indexing="ij"), -1).flip(-1).reshape(-1, 2) for h, w in LEVELS])
     n, res = 4, {}
     g = torch.Generator(device=dev).manual_seed(99)
-    for sigma in (1.0, 2.0, 4.0, 6.0):
-        inv = torch.tensor([[sigma / w, sigma / h] for h, w in LEVELS], device=dev).view(1, 1, 1, L, 1, 2)
+    # The reference's INITIAL offsets are not Gaussian: MSDeformAttn._reset_parameters (ops/modules/ms_deform_attn.py:62-70) sets the
+    # offset bias to a star -- head m looks along direction 2 pi m / M (normalised to |.|_inf = 1), point p sits p + 1 pixels out -- and the
+    # offset weights to zero, so an untrained model samples exactly there on every level (|off|_inf = 1..4 px of the sampled level).
+    # `star`: that pattern; `star_x2`: the same directions twice as far (offsets that have grown, |off|_inf = 2..8 px).
+    thetas = torch.arange(M, dtype=torch.float32, device=dev) * (2.0 * math.pi / M)
+    star = torch.stack([thetas.cos(), thetas.sin()], -1)
+    star = (star / star.abs().max(-1, keepdim=True)[0]).view(1, 1, M, 1, 1, 2) * torch.arange(1, P + 1, device=dev, dtype=torch.float32).view(1, 1, 1, 1, P, 1)
+    px = torch.tensor([[1.0 / w, 1.0 / h] for h, w in LEVELS], device=dev).view(1, 1, 1, L, 1, 2)      # one pixel of each level, normalised
+    cases = [("sigma_%g_px" % sg, sg, 0.0) for sg in sigmas] + [("star", 0.0, 1.0), ("star_x2", 0.0, 2.0)]
+    for name, sigma, star_k in cases:
         sets = []
         for _ in range(nsets):
             a = torch.rand(n, S, M, L, P, generator=g, device=dev) + 1e-5
+            off_px = torch.randn(n, S, M, L, P, 2, generator=g, device=dev) * sigma if sigma > 0 else (star * star_k).expand(n, S, M, L, P, 2)
             sets.append((torch.rand(n, S, M, D, generator=g, device=dev) * 0.01,
-                         (ref.view(1, S, 1, 1, 1, 2) + torch.randn(n, S, M, L, P, 2, generator=g, device=dev) * inv).contiguous(),
+                         (ref.view(1, S, 1, 1, 1, 2) + off_px * px).contiguous(),
                          (a / a.sum((-1, -2), keepdim=True)).contiguous()))
+        gout = torch.rand(n, S, M * D, generator=g, device=dev)
         row = {}
         for policy in ("patch", "window", "adaptive"):
             sda._lib.set_forward_policy(policy)
@@ -864,15 +877,27 @@ def forward_policy_bench(dev, iters=24, nsets=4):
             torch.cuda.synchronize()
             row[policy + "_us"] = e0.elapsed_time(e1) * 1e3 / iters
             row[policy + "_kernel"] = sda._lib.lib().semidetr_msda_last_kernels().decode()
+            # the backward behind it: its gather follows what the slot's forward launches counted (patch gather / lane-per-sample window gather)
+            for i in range(2):
+                v, lo, at = sets[i % nsets]
+                MSDA.ms_deform_attn_backward(v, shapes, starts, lo, at, gout, 64)
+            e0.record()
+            for i in range(iters // 2):
+                v, lo, at = sets[i % nsets]
+                MSDA.ms_deform_attn_backward(v, shapes, starts, lo, at, gout, 64)
+            e1.record()
+            torch.cuda.synchronize()
+            row[policy + "_bwd_us"] = e0.elapsed_time(e1) * 1e3 / (iters // 2)
+            row[policy + "_bwd_kernels"] = sda._lib.lib().semidetr_msda_last_kernels().decode()
         row["far_fraction"] = sda._lib.forward_policy_state()["far_fraction"]
         row["adaptive_vs_patch"] = row["adaptive_us"] / row["patch_us"]
-        row["adaptive_frac_hbm_peak"] = msda_alg_bytes(n, S, False) / (row["adaptive_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-        res["sigma_%g_px" % sigma] = row
+        row["adaptive_frac_hbm_peak"] = msda_alg_bytes(n, S, False, S, L) / (row["adaptive_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        res[name] = row
         del sets
     sda._lib.set_forward_policy("adaptive")
-    res["what"] = ("msda forward, encoder self-attention, bs 4, Lq = S = 22223, %d rotated input sets, %d launches per timing; "
+    res["what"] = ("msda forward (and the backward behind it), encoder self-attention, bs 4, Lq = S = %d, %d levels, %d rotated input sets, %d launches per timing; "
                    "far_fraction = share of level >= 1 samples further than 4 px from their query's centre, as the kernels "
-                   "count it for the dispatcher" % (nsets, iters))
+                   "count it for the dispatcher; star = the reference's initial offsets (ms_deform_attn.py:62-70), star_x2 = twice as far" % (S, L, nsets, iters))
     return res
 
 

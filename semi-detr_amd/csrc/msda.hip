@@ -508,9 +508,14 @@ int allow_big_lds(K kern, size_t bytes, const char *what)
 // Round 5 (the window kernel's geometry halved, tools/r05_crossover.sh): four levels, bs 4: 193 / 213 / 232 / 246 / 255 / 260 us against the patch
 // kernel's 263-270 at sigma 3 / 4 / 5 / 6 / 7 / 8 px -- level beyond 8 px (far share 0.85); one image: 56 / 63 / 68 / 70.5 / 74.5 against 70-71 --
 // level at ~6 px (0.76).  The band moves from 0.60 / 0.70 to 0.72 / 0.80.
-constexpr float kFarToWindow = 0.72f;      // patch -> window when fewer than this share of the samples are far ...
-constexpr float kFarToPatch = 0.80f;       // ... window -> patch above this one
-constexpr float kFarToWindow5 = 0.56f, kFarToPatch5 = 0.66f;      // five levels (COCO-Full pyramid: margin 4 instead of 6)
+// Round 6 (tools/r06_spread.sh, profiles/r06_sample_patterns.txt; Gaussian spreads AND the reference's own initial offset star,
+// ops/modules/ms_deform_attn.py:62-70): four levels, bs 4 -- window 197 / 215 / 229 / 246 us against the patch kernel's 250 / 253 / 253 / 249 at sigma
+// 4 / 5 / 6 / 8 px (far share 0.53 / 0.67 / 0.76 / 0.85): level at ~0.85; star 140 against 222, star x 2 (far share 0.57) 200 against 220.  Five levels:
+// window 233 / 252 / 261 / 274 against 299 / 301 / 301 / 298 -- ahead at every spread measured (round 5's band 0.56 / 0.66 predates the level table and
+// the compact records in the five-level kernel and sent sigma >= 5 px to the patch kernel: 301 instead of 252 us).
+constexpr float kFarToWindow = 0.78f;      // patch -> window when fewer than this share of the samples are far ...
+constexpr float kFarToPatch = 0.86f;       // ... window -> patch above this one
+constexpr float kFarToWindow5 = 0.82f, kFarToPatch5 = 0.90f;      // five levels (COCO-Full pyramid)
 // Per CALL SITE (round 5): the reference builds twelve MSDeformAttn instances per model (transformer.py:609,760) whose learned offsets
 // reach differently far, so the state is kept per (device, slot): the caller names the slot in bits 8..15 of `flags`
 // (SEMIDETR_MSDA_POLICY_SLOT; the Python module gives every instance its own), slot 0 is the state every caller that names none shares.
@@ -619,7 +624,11 @@ int fwd_adapt_next(hipStream_t st, bool allow_window, int slot_id, int levels, F
 // than the window forward crosses the patch forward (tools/r05_gw_sigma.sh, bs 4, whole backward: 572 / 635 / 796 / 976 / 1157 us
 // against 659 / 707 / 834 / 986 / 1111 us at sigma 1 / 2 / 3 / 4 / 5 px; bs 1 level at 3 px): below a far share of ~0.45
 // (sigma ~3.5 px).  Reads the state, counts nothing; no count received yet = the patch gather.
-constexpr float kFarToWindowGather = 0.45f;
+// Round 6, with a round's grad_out rows in LDS (same script): whole backward, four levels, window gather 644 / 794 / 933 / 1091 us against the patch
+// gather's 715 / 830 / 933 / 1062 at sigma 3 / 4 / 5 / 6 px (far share 0.33 / 0.53 / 0.67 / 0.76); the reference's star 490 against 577, but the star
+// twice as far (far share 0.57: half the samples 6 and 8 px out, all of them on the cooperative path) 620 against 574 -- the patch gather profits from
+// the star's regularity.  Five levels: 761 / 910 / 1072 against 856 / 965 / 1088 at sigma 3 / 4 / 5 px, star x 2 794 against 770.  0.45 -> 0.55.
+constexpr float kFarToWindowGather = 0.55f;
 bool slot_samples_are_near(int slot_id)
 {
     const int policy = g_fwd_policy.load(std::memory_order_relaxed);
