@@ -51,8 +51,8 @@ RECIPES = {
 ROT = 6                                                     # distinct input sets per MSDA group: one per layer of a pass
 GRAD_ELEMS = 60_000_000                                     # student DINO-R50 + projector
 HBM_PEAK_GBS = 8000.0                                       # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_JSON = "r05_pmc_traffic.json"                           # written by tools/measure_traffic.py (rocprofv3 --pmc passes)
-TA_JSON = "r05_fwd_enc_TA.json"                             # written by tools/r05_fwd_ta_evidence.sh
+PMC_JSON = "r06_pmc_traffic.json"                           # written by tools/measure_traffic.py (rocprofv3 --pmc passes)
+TA_JSON = "r06_fwd_enc_TA.json"                             # written by tools/r06_fwd_ta_evidence.sh
 
 
 def msda_alg_bytes(N, Lq, backward, S=S, L=L):
@@ -1080,7 +1080,7 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_JSON)))
             except (OSError, ValueError):
                 return None, None
-            for key in (group, group + "_window"):      # the encoder forward has one entry per kernel
+            for key in (group, group + "_patch"):       # the encoder launches have one entry per kernel choice
                 e = pmc.get(key)
                 if e and sorted(e.get("kernels", [])) == sorted(wl.kernels.get(group, [])):
                     return e.get("hbm_bytes_corrected"), ("profiles/" + PMC_JSON + ":" + key +
@@ -1105,7 +1105,7 @@ def main():
         fdur = fg["ms"] * 1e-3 / fg["launches"]
         clock_mhz = torch.cuda.get_device_properties(dev).clock_rate / 1e3 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2400.0
         l1_peak = 256 * 64 * 2400e6 / 1e9
-        # observed clock / TA busy fraction of this kernel: measured by tools/r05_fwd_ta_evidence.sh (rocprofv3 --pmc), read
+        # observed clock / TA busy fraction of this kernel: measured by tools/r06_fwd_ta_evidence.sh (rocprofv3 --pmc), read
         # from the committed summary rather than carried as constants
         try:      # (one entry per forward kernel: the one this run's encoder forward launched)
             ran = (wl.kernels.get("msda_fwd_enc_bs%d_Lq%d" % (wl.n_unsup, wl.S)) or ["msda_fwd_d32"])[0].split("<")[0]

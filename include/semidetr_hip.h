@@ -26,7 +26,7 @@ extern "C" {
 #define SEMIDETR_E_TOOLARGE (-2)    /* an index would overflow the 32-bit arithmetic used on device  */
 #define SEMIDETR_E_NODEVICE (-3)    /* no HIP device available                                        */
 
-#define SEMIDETR_ABI_VERSION 6
+#define SEMIDETR_ABI_VERSION 7
 
 int semidetr_abi_version(void);
 const char *semidetr_last_error(void);
@@ -77,6 +77,14 @@ const char *semidetr_last_error(void);
  * torch.use_deterministic_algorithms(True) is in force).  grad_value is accumulated with fp32 atomics either way, exactly as in
  * the reference (ms_deform_im2col_cuda.cuh:87-159): the BACKWARD's summation order is run-dependent there and here. */
 #define SEMIDETR_MSDA_FIXED_FORWARD 2
+/* Backward only (ABI 7): WHICH kernel computes grad_sampling_loc / grad_attn_weight of an encoder backward, stated by the caller instead of
+ * read from the slot's live counts.  The two gathers agree to fp32 rounding, not bit for bit, and in the reference these two gradients
+ * are deterministic (no atomics: ms_deform_im2col_cuda.cuh:301-403) -- so a caller that wants the backward to follow what was known when the
+ * matching FORWARD ran (the autograd functions do: they ask semidetr_msda_gather_choice right after the forward launch and hand the answer
+ * back here) sets one of the two.  Neither bit: the slot's state at the time of the backward decides (ABI <= 6 behaviour).
+ * SEMIDETR_MSDA_FIXED_FORWARD still wins (patch gather). */
+#define SEMIDETR_MSDA_GATHER_WINDOW (1 << 16)
+#define SEMIDETR_MSDA_GATHER_PATCH (1 << 17)
 int semidetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                               const int64_t *level_start, const float *sampling_loc,
                               const float *attn_weight, int batch, int spatial_size, int num_heads,
@@ -158,7 +166,7 @@ int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, 
  * policy 0 (default, adaptive): both kernels count, in a few workgroups, the share of samples further than 4 px from their
  *   query's pixel centre; launch k's count reaches the host through mapped pinned memory when launch k + 1 OF THE SAME SLOT starts
  *   (no copy command, no synchronisation) and the NEXT dispatch of that slot moves between the kernels with hysteresis (to the
- *   window kernel below 72 %, back above 80 %; five levels 56 % / 66 %).  State is per (device, slot) -- see
+ *   window kernel below 78 %, back above 86 %; five levels 82 % / 90 %).  State is per (device, slot) -- see
  *   SEMIDETR_MSDA_POLICY_SLOT; launches inside a stream capture keep their slot's kernel of the moment and count nothing.  The
  *   first adaptive dispatch on a device allocates the counters (64 KB of device memory, 4 KB of pinned host memory; the two
  *   allocation calls may synchronise that device once).  Launches of ONE slot on two streams of a device at the same time share
@@ -167,7 +175,8 @@ int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, 
  * policy 1: always the patch kernel.   policy 2: the window kernel whenever it applies.   (Process-wide.)
  * The encoder BACKWARD (four levels) reads the same slot: its small-gradient half runs as the lane-per-sample region-window gather
  *   (msda_gw_d32; whole backward 572 / 635 / 796 us against 659 / 707 / 834 us at sigma 1 / 2 / 3 px, bs 4) while the slot's last
- *   count has fewer than 45 % of the samples further than 4 px away (policy 2: always; policy 1 or no count yet: the patch gather).
+ *   count has fewer than 55 % of the samples further than 4 px away (policy 2: always; policy 1 or no count yet: the patch gather) --
+ *   or as SEMIDETR_MSDA_GATHER_WINDOW / _PATCH in the backward's `flags` say (the caller's record of the choice at forward time).
  *   grad_value's summation order is run-dependent either way (fp32 atomics); the two gathers agree to fp32 rounding.
  * If the device does not grant the window kernel its LDS (~150 KB per workgroup) the patch kernel runs instead.
  * semidetr_msda_forward_policy_state[_slot]: for the calling thread's current device and slot (0 without _slot) -- the policy,
@@ -177,6 +186,9 @@ int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, 
 int semidetr_msda_set_forward_policy(int policy);
 int semidetr_msda_forward_policy_state(int *policy, int *mode, float *far_fraction, unsigned *updates);
 int semidetr_msda_forward_policy_state_slot(int slot, int *policy, int *mode, float *far_fraction, unsigned *updates);
+/* What an encoder backward of `slot` issued NOW would pick for its small-gradient half, as the flag to pass later:
+ * SEMIDETR_MSDA_GATHER_WINDOW or SEMIDETR_MSDA_GATHER_PATCH (never 0, never an error: an unknown slot / device answers PATCH). */
+int semidetr_msda_gather_choice(int slot);
 
 /* Names of the device kernels the LAST semidetr_msda_* call of the calling thread launched ("+"-separated, as the
  * profiler prints their base names), so that a benchmark reports what actually ran instead of a hand-kept table. */

@@ -37,6 +37,7 @@ ms_deform_attn_fused_backward = _msda_ext.ms_deform_attn_fused_backward
 fused_supported = _msda_ext.fused_supported
 pyramid_check = _msda_ext.pyramid_check
 mask_extents = _msda_ext.mask_extents
+gather_choice = _msda_ext.gather_choice
 
 if _msda_ext.abi_version() != _lib.lib().semidetr_abi_version():      # a stale front end against a newer library
     raise _lib.NativeLibraryError("semi-detr_amd/_msda_ext*.so was built against ABI %d, libsemidetr_hip.so is ABI %d: rebuild "

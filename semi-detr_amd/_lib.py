@@ -43,6 +43,7 @@ SIGNATURES = {
     "semidetr_msda_set_forward_policy": (c_int, [c_int]),
     "semidetr_msda_forward_policy_state": (c_int, [c_void_p] * 4),
     "semidetr_msda_forward_policy_state_slot": (c_int, [c_int] + [c_void_p] * 4),
+    "semidetr_msda_gather_choice": (c_int, [c_int]),
     "semidetr_match_cost_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [ctypes.POINTER(CostParams), c_void_p]),
     "semidetr_lsap_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "semidetr_lsap_solve": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 6),

@@ -789,7 +789,9 @@ int launch_fast_backward(hipStream_t st, const float *grad_out, const float *val
         bool window_gather = false;
         // (SEMIDETR_MSDA_FIXED_FORWARD: which gather runs must not depend on earlier launches either -- the patch gather)
         // (Lq * M * L * P * 8 bytes per image < 2^32: msda_gw_d32 indexes the sampling data inside an image with 32 bits)
-        if ((L == 4 || L == 5) && P == kPT && (fill_in_gather || SEMIDETR_SEPARATE_FILL) && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && slot_samples_are_near((flags >> 8) & 0xff) &&
+        // (SEMIDETR_MSDA_GATHER_WINDOW / _PATCH: the caller's record of what the slot said when the matching forward ran; neither: its state now)
+        const bool near = (flags & SEMIDETR_MSDA_GATHER_WINDOW) ? true : ((flags & SEMIDETR_MSDA_GATHER_PATCH) ? false : slot_samples_are_near((flags >> 8) & 0xff));
+        if ((L == 4 || L == 5) && P == kPT && (fill_in_gather || SEMIDETR_SEPARATE_FILL) && !(flags & SEMIDETR_MSDA_FIXED_FORWARD) && near &&
             (uint64_t)Lq * M * L * P * 8 < (1ull << 32)) {
             // lane-per-sample gather on region windows (msda_gw.h): 16 x 16 regions, margin 4 on every level, one 1024-thread workgroup per CU
             // (round 5: 1024 threads = 16 waves per CU for the reference contract and the fused prologue without a mask -- 124 / 128 VGPRs
@@ -976,6 +978,11 @@ extern "C" int semidetr_msda_forward_policy_state_slot(int slot, int *policy, in
     if (far_fraction) *far_fraction = sl.last_frac;
     if (updates) *updates = sl.updates;
     return SEMIDETR_OK;
+}
+
+extern "C" int semidetr_msda_gather_choice(int slot)
+{
+    return (slot >= 0 && slot < kPolicySlots && slot_samples_are_near(slot)) ? SEMIDETR_MSDA_GATHER_WINDOW : SEMIDETR_MSDA_GATHER_PATCH;
 }
 
 extern "C" int semidetr_msda_forward_policy_state(int *policy, int *mode, float *far_fraction, unsigned *updates)

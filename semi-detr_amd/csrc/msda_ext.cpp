@@ -141,9 +141,13 @@ int pyramid_check(const at::Tensor &shapes, const at::Tensor &starts, int64_t S)
 // torch.use_deterministic_algorithms(True) is in force -- a forward kernel that does not depend on earlier launches
 int self_attention_flags(const at::Tensor &shapes, const at::Tensor &starts, int Lq, int S, int64_t policy_slot = 0)
 {
-    TORCH_CHECK(policy_slot >= 0 && policy_slot <= 255, "policy_slot must be 0..255, got ", policy_slot);
+    // (the backward calls may carry, OR-ed into the slot number, what gather_choice(slot) answered when the matching forward ran:
+    //  SEMIDETR_MSDA_GATHER_WINDOW / _PATCH, bits 16 / 17 -- the autograd functions do that)
+    constexpr int64_t kGather = SEMIDETR_MSDA_GATHER_WINDOW | SEMIDETR_MSDA_GATHER_PATCH;
+    TORCH_CHECK(policy_slot >= 0 && (policy_slot & ~kGather) <= 255 && (policy_slot & kGather) != kGather,
+                "policy_slot must be 0..255 (optionally | gather_choice(slot)), got ", policy_slot);
     return ((Lq == S && (pyramid_check(shapes, starts, S) & 2)) ? SEMIDETR_MSDA_QUERIES_ARE_PIXELS : 0) |
-           SEMIDETR_MSDA_POLICY_SLOT((int)policy_slot) |
+           SEMIDETR_MSDA_POLICY_SLOT((int)(policy_slot & 0xff)) | (int)(policy_slot & kGather) |
            (at::globalContext().deterministicAlgorithms() ? SEMIDETR_MSDA_FIXED_FORWARD : 0);
 }
 
@@ -397,6 +401,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("level_start_index"), py::arg("reference_points"), py::arg("sampling_offsets"), py::arg("attn_logits"),
           py::arg("grad_output"), py::arg("padding_mask") = py::none(), py::arg("policy_slot") = 0);
     m.def("fused_supported", &fused_supported);
+    m.def("gather_choice", [](int64_t slot) { return semidetr_msda_gather_choice((int)slot); }, py::arg("policy_slot") = 0,
+          "What an encoder backward of this slot issued now would pick for grad_sampling_loc / grad_attn_weight (SEMIDETR_MSDA_GATHER_WINDOW "
+          "or _PATCH): OR it into the backward call's policy_slot and the backward follows what was known at forward time.");
     m.def("mask_extents", &mask_extents, py::arg("padding_mask"), py::arg("spatial_shapes"), py::arg("level_start_index"),
           "(N, L) int32 words vh | vw << 16: level l of image n is padded exactly on rows >= vh / columns >= vw, or -1.  Cached per "
           "(mask, level table) tensors, version and stream; the fused calls fetch it themselves.");

@@ -21,9 +21,11 @@ class MSDeformAttnFunction(Function):
                 attention_weights, im2col_step, policy_slot=0):
         # policy_slot (optional, not in the reference's signature): the call site's slot of the encoder forward-kernel choice
         ctx.im2col_step = im2col_step
-        ctx.policy_slot = policy_slot
         output = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                              sampling_locations, attention_weights, ctx.im2col_step, policy_slot)
+        # The backward's small-gradient kernel follows what the call site's counts said NOW, not whenever the backward runs (the two
+        # gathers agree to fp32 rounding only, and the reference's grad_sampling_loc / grad_attn_weight are deterministic): ADVICE r05
+        ctx.policy_slot = policy_slot | MSDA.gather_choice(policy_slot)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                               attention_weights)
         return output
@@ -51,9 +53,9 @@ class MSDeformAttnFusedFunction(Function):
                 padding_mask=None, policy_slot=0):
         if padding_mask is not None:
             padding_mask = padding_mask.contiguous()
-        ctx.policy_slot = policy_slot
         output = MSDA.ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, reference_points,
                                                    sampling_offsets, attn_logits, padding_mask, policy_slot)
+        ctx.policy_slot = policy_slot | MSDA.gather_choice(policy_slot)      # (see MSDeformAttnFunction.forward)
         ctx.save_for_backward(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
                               attn_logits, padding_mask)
         return output

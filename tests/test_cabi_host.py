@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/semidetr_hip.h but not exported"
     assert sorted(semi_detr_amd._lib.SIGNATURES) == names
-    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 6
+    assert semi_detr_amd._lib.lib().semidetr_abi_version() == 7
     # the tuning / measurement entry points live ONLY in the experiments build (not in what ships)
     extra = _declared_functions("semidetr_hip_experiments.h")
     assert extra == sorted(semi_detr_amd._lib.EXPERIMENT_SIGNATURES) and len(extra) == 3
@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(exp, n), f"{n} missing from libsemidetr_hip_exp.so"
     for n in extra:
         assert not hasattr(handle, n), f"{n} must not be exported by the product library"
-    assert exp.semidetr_abi_version() == 6
+    assert exp.semidetr_abi_version() == 7
 
 
 def _code_object_kernels(path):
@@ -152,7 +152,7 @@ def test_compiled_front_end_is_the_reference_module_surface():
     import MultiScaleDeformableAttention as MSDA
     import semi_detr_amd
     assert type(MSDA.ms_deform_attn_forward).__name__ == "builtin_function_or_method" or "pybind" in repr(MSDA.ms_deform_attn_forward)
-    assert semi_detr_amd.MultiScaleDeformableAttention._msda_ext.abi_version() == 6
+    assert semi_detr_amd.MultiScaleDeformableAttention._msda_ext.abi_version() == 7
     sh, ls = torch.tensor([[2, 3], [1, 2]]), torch.tensor([0, 6])
     assert MSDA.pyramid_check(sh, ls, 8) == 3
     assert MSDA.pyramid_check(sh, ls, 8) == 3                      # cache hit

@@ -461,3 +461,78 @@ def test_forward_inside_a_stream_capture(policy):
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy(), oracle.msda_forward(value2, shp, loc2, attn2), rtol=0, atol=2e-6)
     assert sda._lib.forward_policy_state()["updates"] == before      # the replayed launch counted nothing
+
+
+def test_backward_gather_follows_the_choice_made_at_forward_time():
+    """under the adaptive policy the backward's small-gradient kernel (patch gather / lane-per-sample window gather) used
+    to follow the slot's state at the time of the BACKWARD.  The autograd functions now record `gather_choice(slot)` right after the
+    forward launch and hand it to the backward (SEMIDETR_MSDA_GATHER_WINDOW / _PATCH in `flags`): a call site whose counts change
+    between its forward and its backward still runs the gather its forward knew about -- here across a mode change in both
+    directions -- and the gradients equal the oracle's either way."""
+    import MultiScaleDeformableAttention as MSDA
+    import semi_detr_amd as sda
+    sda._lib.set_forward_policy("adaptive")
+    shapes = [(40, 54), (20, 27), (10, 14), (5, 7)]
+    shp = np.asarray(shapes, np.int64)
+    tsh = _t(shp)
+    tls = _starts(tsh)
+    slot = 21
+
+    def case(sigma, seed):
+        value, _, ref, off, logits, gout = _encoder_case(2, shapes, sigma, seed)
+        loc, attn = _prologue_np(ref, off, logits, shp, P)
+        return value, loc, attn, gout
+
+    near, far = case(1.0, 71), case(14.0, 72)
+
+    def settle(c):
+        for _ in range(8):
+            MSDA.ms_deform_attn_forward(_t(c[0]), tsh, tls, _t(c[1]), _t(c[2]), 64, slot)
+            torch.cuda.synchronize()
+
+    WINDOW, PATCH = 1 << 16, 1 << 17
+    # (autograd runs the backward on its own thread and semidetr_msda_last_kernels is per thread: record it where the call is made)
+    ran, orig_bwd = [], MSDA.ms_deform_attn_backward
+
+    def spy(*a):
+        r = orig_bwd(*a)
+        ran.append(_last())
+        return r
+    MSDA.ms_deform_attn_backward = spy
+    try:
+        _gather_choice_body(MSDA, sda, settle, near, far, tsh, tls, shp, slot, ran, WINDOW, PATCH)
+    finally:
+        MSDA.ms_deform_attn_backward = orig_bwd
+    # a backward call that states nothing keeps the old behaviour: the slot's state now
+    MSDA.ms_deform_attn_backward(_t(far[0]), tsh, tls, _t(far[1]), _t(far[2]), _t(far[3]), 64, slot)
+    assert _last().startswith("msda_gw_d32+"), _last()
+    MSDA.ms_deform_attn_backward(_t(far[0]), tsh, tls, _t(far[1]), _t(far[2]), _t(far[3]), 64, slot | PATCH)
+    assert _last().startswith("msda_bwd_gather_d32+"), _last()
+    with pytest.raises(RuntimeError, match="policy_slot"):
+        MSDA.ms_deform_attn_backward(_t(far[0]), tsh, tls, _t(far[1]), _t(far[2]), _t(far[3]), 64, slot | PATCH | WINDOW)
+
+
+def _gather_choice_body(MSDA, sda, settle, near, far, tsh, tls, shp, slot, ran, WINDOW, PATCH):      # noqa: N803
+    settle(near)
+    assert MSDA.gather_choice(slot) == WINDOW
+    # the autograd function: forward while the slot says "near" ...
+    tv, tl, ta = [_t(a).requires_grad_(True) for a in near[:3]]
+    out = sda.MSDeformAttnFunction.apply(tv, tsh, tls, tl, ta, 64, slot)
+    settle(far)                                        # ... the slot's counts move on before the backward runs
+    assert MSDA.gather_choice(slot) == PATCH
+    out.backward(_t(near[3]))
+    assert ran[-1].startswith("msda_gw_d32+"), ran
+    o_gv, o_gl, o_ga = oracle.msda_backward(near[0], shp, near[1], near[2], near[3])
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(tl.grad.cpu().numpy(), o_gl, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gl).max())))
+    np.testing.assert_allclose(tv.grad.cpu().numpy(), o_gv, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gv).max())))
+    # ... and the other way round: forward while "far", the slot back to "near" before the backward
+    tv, tl, ta = [_t(a).requires_grad_(True) for a in far[:3]]
+    out = sda.MSDeformAttnFunction.apply(tv, tsh, tls, tl, ta, 64, slot)
+    settle(near)
+    assert MSDA.gather_choice(slot) == WINDOW
+    out.backward(_t(far[3]))
+    assert ran[-1].startswith("msda_bwd_gather_d32+"), ran
+    o_gv, o_gl, o_ga = oracle.msda_backward(far[0], shp, far[1], far[2], far[3])
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), o_ga, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(tl.grad.cpu().numpy(), o_gl, rtol=0, atol=1e-4 * max(1.0, float(np.abs(o_gl).max())))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Measure the HBM-side traffic of the MSDA launches bench.py times and write profiles/<round>_pmc_traffic.json (SEMIDETR_ROUND, default r05).
+"""Measure the HBM-side traffic of the MSDA launches bench.py times and write profiles/<round>_pmc_traffic.json (SEMIDETR_ROUND, default r06).
 
 Run on the GPU box:   python tools/measure_traffic.py
 For each event group of the bench step (encoder / decoder, forward / backward, the batch sizes of the step) it runs
@@ -22,20 +22,22 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "traffic")
+RAWM = ["--io", "raw", "--masked"]      # round 6: the headline step = fused prologue + padding mask on bench.py's own inputs (bench.Workload)
 GROUPS = [  # bench group name, probe arguments
-    ("msda_fwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "patch"]),
-    # the same launch through the region-window kernel (what the adaptive policy runs at this sample spread)
-    ("msda_fwd_enc_bs4_Lq22223_window", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "window"]),
-    ("msda_bwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "bwd", "--policy", "patch"]),
-    # ... with the lane-per-sample window gather (round 5; what the adaptive policy runs at this sample spread)
-    ("msda_bwd_enc_bs4_Lq22223_window", ["--shape", "enc", "--bs", "4", "--dir", "bwd", "--policy", "window"]),
-    ("msda_fwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "fwd", "--policy", "patch"]),
-    ("msda_bwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "bwd", "--policy", "patch"]),
-    ("msda_fwd_enc_bs1_Lq22223_window", ["--shape", "enc", "--bs", "1", "--dir", "fwd", "--policy", "window"]),
-    ("msda_bwd_enc_bs1_Lq22223_window", ["--shape", "enc", "--bs", "1", "--dir", "bwd", "--policy", "window"]),
-    ("msda_fwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "fwd"]),
-    ("msda_bwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "bwd"]),
-    ("msda_bwd_dec_bs1_Lq1100", ["--shape", "dec", "--bs", "1", "--lq", "1100", "--dir", "bwd"]),
+    # the encoder launches as the adaptive policy runs them at the bench's sample spread: region-window forward, window gather + region scatter
+    ("msda_fwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "window"] + RAWM),
+    ("msda_bwd_enc_bs4_Lq22223", ["--shape", "enc", "--bs", "4", "--dir", "bwd", "--policy", "window"] + RAWM),
+    ("msda_fwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "fwd", "--policy", "window"] + RAWM),
+    ("msda_bwd_enc_bs1_Lq22223", ["--shape", "enc", "--bs", "1", "--dir", "bwd", "--policy", "window"] + RAWM),
+    # ... and through the patch kernels (what a call site whose offsets have grown runs)
+    ("msda_fwd_enc_bs4_Lq22223_patch", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "patch"] + RAWM),
+    ("msda_bwd_enc_bs4_Lq22223_patch", ["--shape", "enc", "--bs", "4", "--dir", "bwd", "--policy", "patch"] + RAWM),
+    # the reference op contract (no prologue, no mask) on the probe's own inputs, as rounds 1-5 measured it
+    ("msda_fwd_enc_bs4_Lq22223_locattn", ["--shape", "enc", "--bs", "4", "--dir", "fwd", "--policy", "window"]),
+    ("msda_bwd_enc_bs4_Lq22223_locattn", ["--shape", "enc", "--bs", "4", "--dir", "bwd", "--policy", "window"]),
+    ("msda_fwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "fwd"] + RAWM),
+    ("msda_bwd_dec_bs4_Lq1100", ["--shape", "dec", "--bs", "4", "--lq", "1100", "--dir", "bwd"] + RAWM),
+    ("msda_bwd_dec_bs1_Lq1100", ["--shape", "dec", "--bs", "1", "--lq", "1100", "--dir", "bwd"] + RAWM),
     ("msda_fwd_micro_bs2_Lq300", ["--shape", "micro", "--bs", "2", "--dir", "fwd"]),
     ("msda_bwd_micro_bs2_Lq300", ["--shape", "micro", "--bs", "2", "--dir", "bwd"]),
     # the same shape with 8 input sets rotated (> 256 MB: nothing is Infinity-Cache resident), as bench.py's cold micro-benchmark
@@ -62,7 +64,7 @@ def run_pass(counter, args, tag):
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "tools", "msda_probe.py"), "--iters", "3", "--print-kernels"] + args      # a later --iters wins
     env = dict(os.environ, TMPDIR="/tmp", SEMIDETR_EXPERIMENTS="0")      # the PRODUCT library is what is measured
-    p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+    p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
     if p.returncode != 0:
         raise SystemExit("rocprofv3 failed for %s %s:\n%s" % (tag, counter, p.stderr[-2000:]))
     reported = [ln.split("=", 1)[1].strip() for ln in p.stdout.splitlines() if ln.startswith("KERNELS=")]
@@ -98,7 +100,7 @@ def main():
             raise SystemExit("%s: msda kernels in the trace the library did not report: %r" % (group, stray))
         res[group] = {"kernels": rep_f, "per_kernel": kernels, "hbm_bytes_corrected": int(total)}
         print(group, rep_f, "%.1f MB" % (total / 1e6), flush=True)
-    with open(os.path.join(ROOT, "gpurun_out", os.environ.get("SEMIDETR_ROUND", "r05") + "_pmc_traffic.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", os.environ.get("SEMIDETR_ROUND", "r06") + "_pmc_traffic.json"), "w") as f:
         json.dump(res, f, indent=1)
 
 

@@ -29,7 +29,13 @@ def main():
     ap.add_argument("--settle", type=int, default=0, help="synchronised warm-up launches (lets the adaptive forward policy see the data)")
     ap.add_argument("--cold", type=int, default=1, help="rotate this many distinct input sets (8 x 47 MB > the Infinity Cache)")
     ap.add_argument("--check", action="store_true", help="forward only: compare the forced variant's result with the patch kernel's")
+    ap.add_argument("--io", default="locattn", choices=["locattn", "raw"],
+                    help="raw (round 6): the fused-prologue entry points on bench.py's OWN inputs (bench.Workload: reference points, raw offsets "
+                         "sigma 2 px, raw logits) -- what the headline step launches; shapes enc / dec only")
+    ap.add_argument("--masked", action="store_true", help="with --io raw: the padding mask of bench.py's mixed-size batch in every call")
     a = ap.parse_args()
+    if a.io == "raw":
+        return main_raw(a)
     import semi_detr_amd as sda
     import MultiScaleDeformableAttention as MSDA
     sda._lib.set_variant(a.variant if a.fvariant is None else a.fvariant, a.variant)
@@ -97,6 +103,52 @@ def main():
             print("KERNELS=" + sda._lib.lib().semidetr_msda_last_kernels().decode())
         b = bench.msda_alg_bytes(n, lq, bw)
         print(f"{a.shape} bs{n} Lq{lq} {name} variant{a.variant}: {us:9.1f} us  alg {b/1e6:8.1f} MB  "
+              f"{b/us/1e3:8.1f} GB/s  ({b/us/1e3/80:5.1f}% of 8 TB/s)")
+
+
+def main_raw(a):
+    """the fused entry points on the bench step's inputs (bench.Workload), same timing / printing as the reference-contract probe"""
+    import semi_detr_amd as sda
+    import MultiScaleDeformableAttention as MSDA
+    assert a.shape in ("enc", "dec") and a.variant == 0 and a.sigma == 2.0, "--io raw: product kernels on bench.py's inputs (sigma 2 px)"
+    sda._lib.set_forward_policy(a.policy)
+    dev = torch.device("cuda:0")
+    wl = bench.Workload(dev, 1234, recipe="coco10", io="raw", input_sets=max(1, a.cold), masked=a.masked)
+    n, lq = a.bs, (wl.S if a.shape == "enc" else a.lq)
+    mask = wl.mask[n] if a.masked else None
+    turn = [0]
+
+    def pick():
+        turn[0] += 1
+        r = turn[0]
+        return wl.t[("value", n)][r % wl.rot], wl._args(a.shape, n, lq, r), wl.t[("enc_gout", n) if a.shape == "enc" else ("dec_gout", n, lq)][r % wl.rot]
+    runs = []
+    if a.dir in ("fwd", "both"):
+        def f():
+            v, args, _ = pick()
+            MSDA.ms_deform_attn_fused_forward(v, wl.shapes, wl.starts, *args, mask)
+        runs.append(("fwd", f, False))
+    if a.dir in ("bwd", "both"):
+        def b_():
+            v, args, go = pick()
+            MSDA.ms_deform_attn_fused_backward(v, wl.shapes, wl.starts, *args, go, mask)
+        runs.append(("bwd", b_, True))
+    for name, fn, bw in runs:
+        for _ in range(max(a.settle, 6)):      # (synchronised: the adaptive policy and the backward's gather see the counts)
+            fn()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.iters
+        if a.print_kernels:
+            print("KERNELS=" + sda._lib.lib().semidetr_msda_last_kernels().decode())
+        b = bench.msda_alg_bytes(n, lq, bw)
+        print(f"{a.shape} bs{n} Lq{lq} {name} raw{'+mask' if a.masked else ''}: {us:9.1f} us  alg {b/1e6:8.1f} MB  "
               f"{b/us/1e3:8.1f} GB/s  ({b/us/1e3/80:5.1f}% of 8 TB/s)")
 
 
