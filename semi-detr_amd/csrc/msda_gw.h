@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
     const int m = (b % M + (b / M) / kRwHeadRun) % M;
     const int slot0 = (b / M) % regions_bound, n = (b / M) / regions_bound;
 
-    if (zero) {      // side job: clear grad_value, which the scatter launch that FOLLOWS accumulates into
+    if (zero && DBG != 6) {      // side job: clear grad_value, which the scatter launch that FOLLOWS accumulates into  (DBG 6, timing aid: not cleared)
         const int64_t per = (zero_n4 + gridDim.x - 1) / gridDim.x;
         const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < zero_n4 ? lo + per : zero_n4;
         for (int64_t i = lo + tid; i < hi; i += NT) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             const float g_y = inside ? a * (b_ - t_) : 0.f;
             float dot = 0.f;                       // fused epilogue: sum_k a_k g_k over the row (softmax backward)
             if (IO::kSoftmax) dot = LP == 16 ? lp_group_sum(a * g_a, 16) : gw_row_sum(a * g_a, bp_row);
-            if (act) ion.store_px(row, nq, LP, k, lvl, P, Hf, Wf, g_a, g_x, g_y, a, dot);
+            if (act && (DBG != 5 || g_a == 1.2345e30f)) ion.store_px(row, nq, LP, k, lvl, P, Hf, Wf, g_a, g_x, g_y, a, dot);      // (DBG 5, timing aid: nothing stored)
         }
     }
 }
