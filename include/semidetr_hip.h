@@ -172,6 +172,9 @@ int semidetr_msda_mask_extents(void *stream, const unsigned char *padding_mask, 
  *   allocation calls may synchronise that device once).  Launches of ONE slot on two streams of a device at the same time share
  *   its counter pair: the counts may mix, the results do not depend on them.  The choice makes the forward's last bits depend on
  *   timing: SEMIDETR_MSDA_FIXED_FORWARD (or policy 1) for bitwise reproducible forwards.
+ *   LIFETIME of that state: the counters (64 KB of device memory + 4 KB of mapped pinned host memory per device) and the per-slot host words are
+ *   allocated at a device's first adaptive dispatch and live until the process ends -- launches in flight reference them, so no call
+ *   releases them (semidetr_msda_set_forward_policy only changes how dispatches READ them; a device reset invalidates them like any allocation).
  * policy 1: always the patch kernel.   policy 2: the window kernel whenever it applies.   (Process-wide.)
  * The encoder BACKWARD (four levels) reads the same slot: its small-gradient half runs as the lane-per-sample region-window gather
  *   (msda_gw_d32; whole backward 572 / 635 / 796 us against 659 / 707 / 834 us at sigma 1 / 2 / 3 px, bs 4) while the slot's last

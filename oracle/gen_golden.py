@@ -25,8 +25,9 @@ What is imported from the reference (by file path, with stub registries for the 
   * detr_ssod/utils/hooks/mean_teacher.py (MeanTeacher, driven through before_run / before_train_iter / after_train_iter
     with a fake runner; stubs: mmcv.parallel.is_module_wrapper, mmcv.runner.hooks.HOOKS / Hook, ..logger.log_every_n)
 The assignment inside HungarianAssigner.assign comes from scipy.optimize.linear_sum_assignment (scipy 1.15.3, a third-party
-dependency the reference does not vendor), exactly as hungarian_assigner.py:136 calls it.  The pseudo-label filter needs all
-of mmdet to import, so that fixture restates dino_detr_ssod.py:918-939 with the same torch calls.
+dependency the reference does not vendor), exactly as hungarian_assigner.py:136 calls it.  The pseudo-label fixture (pseudo.npz) comes
+from the reference's OWN `DinoDetrSSOD.extract_teacher_info` (dino_detr_ssod.py:899-939), imported with stubs for the mmdet / mmcv base
+classes it does not touch and called unbound on a fake teacher (see `gen_pseudo` below) -- it is not a restatement.
 """
 import importlib.util
 import os
