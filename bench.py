@@ -359,10 +359,21 @@ class Workload:
         self.record = record
         sda = self.sda
         ns, nu, Sx = self.n_sup, self.n_unsup, self.S
+
+        def new_batch_masks(*ns_):
+            """In training every batch brings its own padding-mask tensor (transformer.py:1268-1288), so the fused path's per-mask
+            summary launch (semidetr_msda_mask_extents, cached per mask tensor by the front end) runs once per batch -- three
+            times per step: labeled batch, unlabeled weak (teacher), unlabeled strong (student).  A bench that kept ONE mask
+            tensor alive across steps would never pay it: fresh tensors here, inside the timed region."""
+            for n_ in ns_:
+                if self.masked:
+                    self.mask[n_] = self.mask[n_].clone()
+        new_batch_masks(ns, nu)
         self._timed("ema", 1, 12 * self.n_params, lambda: sda.ema_update_(self.teacher, self.student, 0.999))
         q, qd = NUM_QUERY, NUM_QUERY + DN_PAD
         self._fwd("enc", ns, Sx, 6); self._fwd("dec", ns, qd, 6)           # supervised student forward
         self._fwd("enc", nu, Sx, 6); self._fwd("dec", nu, q, 6)            # teacher simple_test
+        new_batch_masks(nu)                                               # (the student's strong-augmented views: another batch)
         self._timed("pseudo_label", 1, 0, self._pseudo)
         if not reuse_encoder:
             self._fwd("enc", nu, Sx, 6)                                    # student no-grad forward: encoder ...
