@@ -107,7 +107,7 @@ struct LocAttnIO {
         (void)nq; (void)l;
         return RawXYc{ld_stream2(loc + (row * LP + k) * 2)};
     }
-    template <typename R>
+    template <bool POINTS = false, typename R>
     __device__ __forceinline__ void finish_xy_c(const RawXYc &r, R nq, int l, int P, float invW, float invH, float &x, float &y) const
     {
         (void)nq; (void)l; (void)P; (void)invW; (void)invH;
@@ -115,7 +115,7 @@ struct LocAttnIO {
         y = r.xy.y;
     }
     // g_x, g_y = d/d (pixel x, pixel y) of the sample; the reference contract returns d/d (normalised location) = that x (W, H)
-    template <typename R>
+    template <bool POINTS = false, typename R>
     __device__ __forceinline__ void store_px(R row, R nq, int LP, int k, int l, int P, float Hf, float Wf, float g_a, float g_x,
                                              float g_y, float a, float dot) const
     {
@@ -249,11 +249,14 @@ struct RawIO {
     {
         return RawXYc{ld_stream2(off + (row * LP + k) * 2), buf_ld2(image_rsrc(ref, ref_bytes), (unsigned)((nq * L + l) * ref_dim) * 4u)};
     }
-    template <typename R>
+    // POINTS (round 6): the caller has established that ref_dim == 2 -- the box branch, a LOAD inside a rarely taken branch of a hot loop,
+    // is compiled out (such a branch costs although it is never taken: every basic-block boundary around a load makes the waits for the
+    // loads in flight conservative; msda_gw_d32 242 -> 232 us with its rare-case branches gone, the masked msda_rw_d32 190 -> 181)
+    template <bool POINTS = false, typename R>
     __device__ __forceinline__ void finish_xy_c(const RawXYc &r, R nq, int l, int P, float invW, float invH, float &x, float &y) const
     {
         float sx = invW, sy = invH;
-        if (ref_dim == 4) {      // (wave-uniform)
+        if (!POINTS && ref_dim == 4) {      // (wave-uniform)
             const float2 wh = *reinterpret_cast<const float2 *>(ref + (nq * L + l) * ref_dim + 2);
             const float ip = 0.5f * fast_rcp((float)P);
             sx = ip * wh.x;
@@ -264,13 +267,13 @@ struct RawIO {
     }
     // g_x, g_y = d/d (pixel x, pixel y) of the sample.  Points: offsets are in pixels of the level (ms_deform_attn.py:102-105), so the
     // offset gradient IS the pixel gradient -- no x W / W round trip (store_with_dot multiplies by W and by v_rcp_f32(W))
-    template <typename R>
+    template <bool POINTS = false, typename R>
     __device__ __forceinline__ void store_px(R row, R nq, int LP, int k, int l, int P, float Hf, float Wf, float g_a, float g_x,
                                              float g_y, float a, float dot) const
     {
         st_stream1(glogit + row * LP + k, a * (g_a - dot));      // softmax backward: a_k * (g_k - sum_j a_j g_j)
         float2 g = make_float2(g_x, g_y);
-        if (ref_dim != 2) {
+        if (!POINTS && ref_dim != 2) {
             const float2 wh = *reinterpret_cast<const float2 *>(ref + (nq * L + l) * ref_dim + 2);
             const float ip = 0.5f * fast_rcp((float)P);
             g = make_float2(g_x * Wf * wh.x * ip, g_y * Hf * wh.y * ip);
@@ -336,7 +339,8 @@ struct RawIO {
 
 // Padding mask for the kernels that LOAD / scatter through byte offsets (forward, strips backward, gather): corners whose
 // pixel is masked become kOob.  (x, y) -> top-left pixel exactly as sample_setup_oob derives it.  `me` = io.mask_ext(n, level).
-template <typename IO>
+// BYTES = false (round 6): the caller has established that every level of the image is summarised -- the byte path is compiled out
+template <typename IO, bool BYTES = true>
 __device__ __forceinline__ void mask_corners_oob(const IO &io, const MaskExt me, int n, float x, float y, int H, int W, int st,
                                                  unsigned (&off)[4])
 {
@@ -351,10 +355,12 @@ __device__ __forceinline__ void mask_corners_oob(const IO &io, const MaskExt me,
         off[3] = (y1 || x1) ? kOob : off[3];
         return;
     }
-    const int pix = st + h0 * W + w0;
+    if constexpr (BYTES) {
+        const int pix = st + h0 * W + w0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if (off[c] != kOob && io.masked(n, pix + (c & 1) + (c >> 1) * W)) off[c] = kOob;
+        for (int c = 0; c < 4; ++c)
+            if (off[c] != kOob && io.masked(n, pix + (c & 1) + (c >> 1) * W)) off[c] = kOob;
+    }
 }
 // ... and for the scatter kernels, which hold level-local pixel indices (or -1) of the four corners of the cell at (h0, w0)
 template <typename IO>

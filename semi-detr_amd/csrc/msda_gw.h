@@ -190,6 +190,13 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
     const unsigned row_bytes = (unsigned)rs * 4u, head_b = (unsigned)(m * kD) * 4u;
 
     const int Hb_k = Hb, Wb_k = Wb, nrx_k = nrx, nry_k = nry;
+    // The RARE cases -- reference BOXES (ref_dim 4; never with pixel queries in DETR) and levels whose mask is not a summarised band (their
+    // bytes decide) -- are loads inside rarely taken branches of the staging, the round loop and the store.  Never taken, they still cost 4 %
+    // (242 -> 232 us, round 6: the waits for the loads in flight turn conservative around every such block).  So the region loop exists twice for
+    // the fused prologue: kSimple (points + every level of my image summarised: workgroup-uniform, known before the first region) without
+    // any of them, and the general one.
+    auto run_regions = [&](auto simple_tag) {
+    constexpr bool kSimple = decltype(simple_tag)::value;
     for (int reg = slot0; reg < nregions; reg += regions_bound) {
         // (the region grid's sizes through an empty asm: the reciprocals of the divisions by them are rebuilt per region instead of being
         //  held -- and at 1024 threads spilled -- for the whole kernel, as in msda_rw_d32)
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                     const unsigned goff = ok ? (unsigned)(sts[l] + py * Ws[l] + px) * row_bytes + lane_bs : kOob;
                     if constexpr (MASK) {
                         smk[nst] = 0u;
-                        if (ves[l] < 0) smk[nst] = mask_n[ok ? sts[l] + py * Ws[l] + px : 0];
+                        if (!kSimple && ves[l] < 0) smk[nst] = mask_n[ok ? sts[l] + py * Ws[l] + px : 0];
                     }
                     sv[nst++] = DBG == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : buf_ld4(vr, goff);
                     r += RPS;
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
 #pragma unroll
                 for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
                     if constexpr (MASK) {      // a level whose mask is not a summarised band: the bytes loaded beside the rows decide
-                        if (ves[l] < 0 && smk[ist] != 0) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (!kSimple && ves[l] < 0 && smk[ist] != 0) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                     if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8s * 16) = sv[ist];
                     ++ist;
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             const float4 lt = gtab[lvl];               // my level: (float)H, (float)W, 1 / H, 1 / W
             const float Hf = lt.x, Wf = lt.y;
             float x, y;
-            ion.finish_xy_c(cur.rxy, nq, lvl, P, lt.w, lt.z, x, y);
+            ion.template finish_xy_c<kSimple>(cur.rxy, nq, lvl, P, lt.w, lt.z, x, y);
             const float raw = cur.raw;
             float a;                                                // fused prologue: softmax over the LP lanes of my row
             if constexpr (LP == 16 || !IO::kSoftmax) {
@@ -430,7 +437,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
                     int ve_my = ves[0];
 #pragma unroll
                     for (int l = 1; l < KL; ++l) ve_my = lvl == l ? __builtin_amdgcn_readfirstlane(ves[l]) : ve_my;
-                    mask_corners_oob(io, MaskExt{ve_my}, n, x, y, myH, myW, myst, foff);
+                    mask_corners_oob<IO, !kSimple>(io, MaskExt{ve_my}, n, x, y, myH, myW, myst, foff);
                 }
             }
             const unsigned long long fb = DBG == 4 ? 0ull : __ballot(far);
@@ -481,7 +488,17 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             const float g_y = inside ? a * (b_ - t_) : 0.f;
             float dot = 0.f;                       // fused epilogue: sum_k a_k g_k over the row (softmax backward)
             if (IO::kSoftmax) dot = LP == 16 ? lp_group_sum(a * g_a, 16) : gw_row_sum(a * g_a, bp_row);
-            if (act && (DBG != 5 || g_a == 1.2345e30f)) ion.store_px(row, nq, LP, k, lvl, P, Hf, Wf, g_a, g_x, g_y, a, dot);      // (DBG 5, timing aid: nothing stored)
+            if (act && (DBG != 5 || g_a == 1.2345e30f)) ion.template store_px<kSimple>(row, nq, LP, k, lvl, P, Hf, Wf, g_a, g_x, g_y, a, dot);      // (DBG 5, timing aid: nothing stored)
         }
+    }
+    };
+    if constexpr (IO::kSoftmax) {
+        bool simple = io.ref_dim == 2;
+#pragma unroll
+        for (int l = 0; l < KL; ++l) simple = simple && (!MASK || ves[l] >= 0);
+        if (simple) run_regions(std::true_type());
+        else run_regions(std::false_type());
+    } else {
+        run_regions(std::false_type());      // (the reference contract has no such branches)
     }
 }

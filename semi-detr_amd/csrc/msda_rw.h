@@ -364,6 +364,13 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     const char *const wbase = lds + j8 * 16;
 
     const int Hb_k = Hb, Wb_k = Wb, nrx_k = nrx, nregions = nry * nrx;
+    // MASK: a level whose mask is not a summarised band (MaskExt < 0) is handled through its BYTES -- loads inside branches of the staging, the
+    // level-0 records and the out-of-window loop.  Never taken for the masks DETR builds, those branches still cost the masked kernel 5 % (190
+    // -> 181 us, round 6: every basic-block boundary around a load is a full s_waitcnt, which also drains the prefetched sampling data and the
+    // level-0 corner loads in flight).  So the region loop exists twice: without any byte path when all levels of my image are summarised
+    // (workgroup-uniform, known before the first region), with them otherwise.
+    auto run_regions = [&](auto bytes_tag) {
+    constexpr bool kBytes = MASK && decltype(bytes_tag)::value;
     for (int reg = slot0; reg < nregions; reg += regions_bound) {
         int Hb_r = Hb_k, Wb_r = Wb_k, nrx_r = nrx_k;      // TUNE + 800: ... and the reciprocals of the divisions by these
         if ((TUNE / 100) & 8) asm volatile("" : "+s"(Hb_r), "+s"(Wb_r), "+s"(nrx_r));
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         // (a level with a summary needs no bytes: wave-uniform branch; a row that is not loaded reads byte 0 and ignores it)
                         if constexpr (MASK) {
                             smk[nst] = 0u;
-                            if (ves[l] < 0) smk[nst] = mask_n[ok ? sts[l] + py * Ws[l] + px : 0];
+                            if (kBytes && ves[l] < 0) smk[nst] = mask_n[ok ? sts[l] + py * Ws[l] + px : 0];
                         }
                         sv[nst++] = buf_ld4(vr, goff);
                         r += RPS;
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                     for (int s = 0; s < (rows_ + RPS - 1) / RPS; ++s) {
                         if constexpr (MASK) {      // a padded pixel's row is staged as zeros: value.masked_fill(mask, 0).  Summarised levels never
                             // loaded theirs (above); a level whose mask has another form carries the bytes it loaded beside the rows
-                            if (ves[l] < 0 && smk[ist] != 0) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (kBytes && ves[l] < 0 && smk[ist] != 0) sv[ist] = make_float4(0.f, 0.f, 0.f, 0.f);
                         }
                         if (r < rows_) *reinterpret_cast<float4 *>(lds + (Wn::row0(l) + r) * 128 + j8s * 16) = sv[ist];
                         ++ist;
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         // (kTab: the summary already is the valid extent above; bit 31 of the table word = this level's bytes decide)
                         const int ve0 = kTab ? 0 : ves[0], vh0 = kTab ? -1 : ext_vh(ve0), vw0 = kTab ? -1 : ext_vw(ve0);
                         bool bytes = inside;
-                        if constexpr (kTab) bytes = inside && T2[p].w < 0;
+                        if constexpr (kTab) bytes = kBytes && inside && T2[p].w < 0;
                         if (vh0 >= 0) {
                             const bool py0 = h0 >= vh0, py1 = h0 + 1 >= vh0, px0 = w0 >= vw0, px1 = w0 + 1 >= vw0;
                             c_tl = c_tl && !(py0 || px0);
@@ -1059,7 +1066,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                         bool c_tl = ok && top && lef, c_tr = ok && top && rig, c_bl = ok && bot && lef, c_br = ok && bot && rig;
                         const int pix = tl[i].z + h0 * W_ + w0;
                         if constexpr (MASK) {      // padded corners read as zero: the valid extent above, or (bit 31) the level's bytes
-                            if (tl[i].w < 0 && ok) {
+                            if (kBytes && tl[i].w < 0 && ok) {
                                 const unsigned char *gp = mask_of_image() + pix;
                                 c_tl = c_tl && !gp[0];      // (left to right: a corner outside the level is never dereferenced)
                                 c_tr = c_tr && !gp[1];
@@ -1144,6 +1151,18 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             lap(9);                                // 9: results
         }
         if (DBG == 1 && tid == 0) SEMIDETR_DBG_ADD(11, 1);
+    }
+    };
+    if constexpr (MASK && kTab) {
+        bool any_bytes = false;
+#pragma unroll
+        for (int l = 0; l < KL; ++l) any_bytes = any_bytes || ves[l] < 0;
+        if (any_bytes) run_regions(std::true_type());
+        else run_regions(std::false_type());
+    } else if constexpr (MASK) {      // (the five-level instantiation keeps ONE loop with the byte paths: twice it spilled at its 128 registers)
+        run_regions(std::true_type());
+    } else {
+        run_regions(std::false_type());
     }
     if (sampled) fwd_stats_add(fs, st_far, st_total, 2u);
     // the launch's first workgroup hands the previous launch's counts to the host when it is done (see msda_fwd_d32)
