@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NT, 1) void msda_gw_d32(
             const Pre cur = nxt;
             const int q = cur.q;
             if (!__any(q >= 0)) break;     // queries are dealt out in order: a wave without one has none later either
-            if (round + 1 < nrounds) fetch(round + 1, nxt);
+            if (SEMIDETR_BRFREE || round + 1 < nrounds) fetch(round + 1, nxt);      // (a slot past the region's last query reads query 0 and stores nothing)
             const bool act = q >= 0;
             const int qs = act ? q : 0;
             const unsigned nq = (unsigned)qs, row = nq * (unsigned)M + (unsigned)m;      // (inside my image: `ion`)

@@ -43,6 +43,14 @@
 // SEMIDETR_MSDA_QUERIES_ARE_PIXELS and num_levels == KL.
 #pragma once
 
+// Round 6: NO BRANCH AROUND LOADS IN THE ROUND LOOPS of the window kernels (msda_rw_d32 forward, msda_gw_d32).  The next round's sampling data
+// is requested unconditionally (a lane / a last round without a query reads query 0 of the image and uses nothing of it) and the window loop,
+// which issues the level-0 corner loads, is not wrapped in the rare "plain round" test.  A branch around a load is a basic-block boundary at
+// which the waits for everything in flight turn conservative: forward 185 -> 179 us, and the compiler stops holding two versions of the
+// round's state -- 168 -> 129 VGPRs (reference contract), 165 -> 141 (fused + mask).  0 = round 5's control flow (A/B: tools/ab_build.sh).
+#ifndef SEMIDETR_BRFREE
+#define SEMIDETR_BRFREE 1
+#endif
 constexpr int kRwHeadRun = 16;      // head rotation of the region kernels (see tile_of_block)
 
 // Window geometry at compile time.  Level l of a halving pyramid sees the region as (RTH >> l) x (RTW >> l) pixels;
@@ -199,6 +207,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
     char *const recs = lds + Wn::total * 128;
     constexpr bool kTab = ((TUNE / 100) & 64) != 0, kQList = ((TUNE / 100) & 128) != 0, kCompact = ((TUNE / 100) & 256) != 0;
     static_assert(!kCompact || (kTab && !GATHER && TUNE % 10 == 0), "compact out-of-window records: forward, level table, nothing pre-issued");
+    // (round 6, SEMIDETR_BRFREE) the window loop -- with the level-0 corner loads issued inside it -- is not wrapped in the "plain round"
+    // branch: a plain round (rare: more than a third of the samples outside their windows) points every record at the zero rows and runs it
+    // for nothing, the common round has one basic block less around loads in flight
+    constexpr bool kLoopAlways = SEMIDETR_BRFREE && kCompact;
     static_assert(!kTab || (((TUNE / 100) & 2) && ((TUNE / 100) & 16) && !GATHER && H0 < 0), "the level table serves the lean forward with split loads");
     // level table: per level {H, W, start, window row0 | window rows - 1, window columns - 1, window pitch, window origin y |
     //                          window origin x, (float)H, (float)W, -}; then the query list
@@ -473,9 +485,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             for (int p = 0; p < NPASS; ++p) {
                 const int k = j8 + 8 * p;
                 rx[p] = ry[p] = ra[p] = 0.f;
-                if (qq >= 0 && k < KLP) {
+                if ((SEMIDETR_BRFREE && kView && KLP % 8 == 0) || (qq >= 0 && k < KLP)) {
                     // (kView: inside my image, 32-bit index arithmetic on the image's view of the tensors)
-                    const typename std::conditional<kView, unsigned, int64_t>::type nq = kView ? (int64_t)qq : (int64_t)n * Lq + qq, row = nq * M + m;
+                    const int qc = (SEMIDETR_BRFREE && kView) ? max(qq, 0) : qq;
+                    const typename std::conditional<kView, unsigned, int64_t>::type nq = kView ? (int64_t)qc : (int64_t)n * Lq + qc, row = nq * M + m;
                     if constexpr (kSplitLoad) {
                         rr[p] = iov.load_xy_raw(row, nq, KLP, k, k / P);
                     } else {
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             } else {
                 q = slot_query((round + 1) * G + oc);
             }
-            if (round + 1 < nrounds) load_round(q, j8);
+            if ((SEMIDETR_BRFREE && kView) || round + 1 < nrounds) load_round(q, j8);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my wave's records are written
 
             // out-of-window samples of this wave: per octet a mask over (pass, lane)
@@ -804,6 +817,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                             *reinterpret_cast<float4 *>(orec + (k - kRec0) * 16) =
                                 inside ? make_float4(sub_rn(w, w0f), sub_rn(h, h0f), sa[p], __int_as_float(((int)h0f + 1) | (((int)w0f + 1) << 15)))
                                        : make_float4(0.f, 0.f, 0.f, __int_as_float(0x40000000));      // (bit 30: no sample; the float 2.0)
+                            if constexpr (kLoopAlways) {      // ... and its two window offsets at the zero rows: the window loop runs over them (adds 0 x finite)
+                                const unsigned z0 = kZ0 + (unsigned)cls * 128u, z1 = kZ0 + (unsigned)(1 - cls) * 128u;
+                                if constexpr (kWide) *reinterpret_cast<uint2 *>(orec + kOffAt + (k - kRec0) * 8) = make_uint2(z0, z1);
+                                else *reinterpret_cast<unsigned *>(orec + kOffAt + (k - kRec0) * 4) = (z0 >> 4) | ((z1 >> 4) << 16);
+                            }
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -951,7 +969,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
             constexpr bool kNoLoop = DBG == 3 || DBG == 7 || DBG == 8;
             if (FG && !kNoFine) fine_issue(0);
             lap(6);                                // 6: next round's loads issued, masks, pre-issued corner loads
-            if (!plain_round && !kNoLoop) {
+            if ((kLoopAlways || !plain_round) && !kNoLoop) {
                 // ---- the common case: every corner from LDS, in the order (top, sw), (top, !sw), (bottom, sw), (bottom, !sw)
 #pragma unroll
                 for (int k = FG ? P : 0; k < KLP; ++k) {
@@ -1012,7 +1030,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? NT / 256 : 2)) void msda_rw_d32(  
                 }
             }
             if (FG && !kNoFine) {
-                if (plain_round || kNoLoop) {      // the LDS loop (and its hand-over points) was skipped
+                if ((!kLoopAlways && plain_round) || kNoLoop) {      // the LDS loop (and its hand-over points) was skipped
 #pragma unroll
                     for (int g = 1; g < kFineGroups; ++g) { fine_consume(); fine_issue(g * kFineN); }
                 }
