@@ -163,8 +163,10 @@ constexpr int kMaxLevels = 32;
 #define SEMIDETR_RW_TUNE5 47910  // (round 5: as four levels -- split loads, level table, query list, compact records, one out-of-window sample per trip;
                                  //  the wide window offsets do not fit beside 120 octets' records.  The fused prologue keeps round 4's configuration (with table +
                                  //  query list it spills at 128 registers): SEMIDETR_RW_TUNE5_RAW / _MASK)
-#define SEMIDETR_RW_TUNE5_RAW 1110
-#define SEMIDETR_RW_TUNE5_MASK 1110
+#ifndef SEMIDETR_RW_TUNE5_RAW
+#define SEMIDETR_RW_TUNE5_RAW 47910      // (round 6: with no branch around the round loop's loads -- msda_rw.h SEMIDETR_BRFREE -- the fused prologue's five-level
+#define SEMIDETR_RW_TUNE5_MASK 47910     //  instantiations fit the table / list / compact-record configuration too: 112 / 113 VGPRs, no spill; rounds 4-5: 1110)
+#endif
                                  // 1110 =     (16 waves per CU, 128 VGPRs): ONE sample between scheduling barriers (three passes of samples per lane) and
                                  //     + 800: everything derived from the thread index rebuilt per round / region.  768 threads: 223 / 232 / 273 us
                                  //     at sigma 1 / 2 / 3 px, 1024: 208 / 225 / 255.  (Four levels at 1024 threads would have to give up margin 6
