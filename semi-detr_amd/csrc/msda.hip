@@ -136,9 +136,9 @@ constexpr int kMaxLevels = 32;
                                  // where the loads are issued (a round early, waiting for them): fused-prologue forward 189.8 -> 188.0 us
 #endif
 #ifndef SEMIDETR_RW_SB_LOCATTN
-#define SEMIDETR_RW_SB_LOCATTN 10     // added to SEMIDETR_RW_TUNE for the reference contract: 10 x (samples between barriers - 2).  Round 6: THREE samples
-                                      // (four sit exactly at 168 VGPRs and spilled 8 once FwdStats became one pointer; three and four measured level in round 5:
-                                      //  163.1 / 169.8 / 190.4 against 163.9 / 169.2 / 188.1 us at sigma 1 / 2 / 3 px, profiles/r05_forward_timing_aids.txt section 8)
+#define SEMIDETR_RW_SB_LOCATTN 0      // added to SEMIDETR_RW_TUNE for the reference contract: 10 x (samples between barriers - 2).  Round 5: 20 (four
+                                      // samples: -1.3 ... -2 %); round 6, with the branch-free round loop (msda_rw.h SEMIDETR_BRFREE; 129 VGPRs at any spacing):
+                                      // two / three / four samples 162.5-163.8 / 168.5-171.0 / 164.3-165.4 us (tools/r05_ab_kern.sh, same box) -> two, like RawIO
 #endif
 #ifndef SEMIDETR_RW_TUNE_MASK
 #define SEMIDETR_RW_TUNE_MASK 98320   // the instantiation with the padding mask (166 VGPRs; with the table but without the compact records it spills)
